@@ -1,0 +1,148 @@
+/*
+ * rt_amd.h -- C ABI of the MI355X path-tracing kernel library
+ * (libraytrace_amd.so).  Plain C, plain pointers and sizes.
+ *
+ * The reference (inrick/raytrace, C renderer) has no plugin or FFI layer: all
+ * of it is one translation unit of static functions.  Its one seam is the
+ * pthread entry point `static void* render(void*)` with its `render_arg`
+ * (c/main.c:437-483), called once per row band by `raytrace()`
+ * (c/main.c:510-545).  Every entry point below replaces a piece of that
+ * seam; each comment names the reference lines it stands in for.
+ *
+ * Threading: one rt_ctx per device (or several); calls on one ctx must not
+ * overlap, calls on different contexts may run from different host threads.
+ * Errors: every function returns 0 on success or an RT_ERR_* code and never
+ * aborts; rt_last_error() gives the text for the calling thread.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_AMD_ABI_VERSION 1
+
+enum {
+  RT_OK = 0,
+  RT_ERR_ARG = 1,      /* bad argument (null pointer, zero size, row range) */
+  RT_ERR_HIP = 2,      /* a HIP runtime call failed; see rt_last_error()    */
+  RT_ERR_NO_SCENE = 3, /* render before rt_scene_upload                     */
+  RT_ERR_NOMEM = 4,
+  RT_ERR_LIMIT = 5     /* a size is beyond what the kernels support         */
+};
+
+/* material kinds, numbered as material_t of c/structs.c:10-14 */
+enum { RT_MATTE = 0, RT_METAL = 1, RT_DIELECTRIC = 2 };
+
+/* One sphere: the fields of `sphere` + `material` (c/structs.c:16-36) with
+ * the union flattened.  param = fuzz (metal) or ref_idx (dielectric). 36 B. */
+typedef struct {
+  float center[3];
+  float radius;
+  int32_t type;
+  float albedo[3];
+  float param;
+} rt_sphere;
+
+/* The eight fields of `camera` (c/structs.c:43-47), same order, 88 B. */
+typedef struct {
+  float llc[3], horiz[3], vert[3], origin[3], u[3], v[3], w[3];
+  float lens_radius;
+} rt_camera;
+
+enum {
+  RT_KERNEL_MEGA = 0,      /* one persistent lane per pixel, whole bounce loop in one kernel */
+  RT_KERNEL_WAVEFRONT = 1  /* material-sorted wavefront stages (comparison variant)          */
+};
+
+/* What one call renders: the fields of render_arg (c/main.c:437-444) other
+ * than the pointers, generalised from one contiguous band to a set of
+ * equally spaced row tiles so that GPUs can interleave.  Tile t covers image
+ * rows [row0 + t*tile_stride, +tile_rows) clipped to ny; rows are counted
+ * from the top as in the output buffer (c/main.c:458-479).  Outputs hold the
+ * tiles back to back, top row first, no padding. */
+typedef struct {
+  uint32_t nx, ny;          /* full image size (pixel coordinates are global)   */
+  uint32_t row0;            /* first row of tile 0                              */
+  uint32_t tile_rows;       /* rows per tile                                    */
+  uint32_t tile_stride;     /* rows between the starts of consecutive tiles     */
+  uint32_t n_tiles;
+  uint32_t nsamples;        /* render_arg.nsamples                              */
+  uint32_t max_depth;       /* reference: 50 (c/main.c:262)                     */
+  float tmin;               /* reference: (float)0.001 (c/main.c:264)           */
+  uint32_t seed;            /* seed of the counter generator                    */
+  uint32_t kernel;          /* RT_KERNEL_*                                      */
+  uint32_t flags;           /* reserved, 0                                      */
+} rt_job;
+
+/* Device-side event counts accumulated by the kernels since the last reset. */
+typedef struct {
+  uint64_t paths;           /* camera paths finished                            */
+  uint64_t segments;        /* closest-hit scans (calls of hit_scene, c/main.c:264) */
+  uint64_t tests;           /* ray-sphere filter tests executed in those scans  */
+  uint64_t candidates;      /* tests that went on to the exact evaluation       */
+} rt_counters;
+
+typedef struct rt_ctx rt_ctx;
+
+/* number of rows the job covers (sum over tiles after clipping) */
+uint32_t rt_job_rows(const rt_job *job);
+
+const char *rt_last_error(void);
+int rt_abi_version(void);
+int rt_device_count(int *count);
+
+/* One context per device; replaces the per-thread state of c/main.c:531-539. */
+int rt_ctx_create(int device, rt_ctx **out);
+int rt_ctx_destroy(rt_ctx *ctx);
+/* Run the context's work on a caller-owned hipStream_t (NULL = the context's
+ * own stream).  Lets a host framework order renders with its own work. */
+int rt_ctx_set_stream(rt_ctx *ctx, void *hip_stream);
+int rt_ctx_synchronize(rt_ctx *ctx);
+
+/* Copies the sphere list to the device: stands in for the `scene*` that
+ * raytrace() hands every render thread (c/main.c:499-501, 520).  Host
+ * pointer; the list is immutable until the next upload. */
+int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, size_t n);
+
+/* render() of c/main.c:446-483 for the rows of `job`, asynchronous on the
+ * context's stream.  All pointers are DEVICE pointers sized for
+ * rt_job_rows(job)*nx pixels: rgb8 3 bytes per pixel (required); the others
+ * may be NULL: linear = 3 floats per pixel, mean radiance before the square
+ * root; first_hit = sphere index hit by sample 0's camera ray or -1;
+ * hit_sum = sum over samples of (first-hit index + 1), wrapping. */
+int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_job *job,
+                     uint8_t *d_rgb8, float *d_linear, int32_t *d_first_hit,
+                     uint32_t *d_hit_sum);
+
+/* The same through context-owned device buffers, then copied to HOST
+ * pointers; returns when the copies are done.  This is the form the
+ * reference's caller would bind: buf/len of render_arg (c/main.c:438-439). */
+int rt_render_host(rt_ctx *ctx, const rt_camera *cam, const rt_job *job,
+                   uint8_t *h_rgb8, float *h_linear, int32_t *h_first_hit,
+                   uint32_t *h_hit_sum);
+
+/* Duration of the kernels of the last finished render on this context,
+ * measured with HIP events on the stream they ran on (milliseconds). */
+int rt_ctx_last_kernel_ms(rt_ctx *ctx, float *ms);
+int rt_ctx_counters(rt_ctx *ctx, rt_counters *out, int reset);
+
+/* ---- unit-level entry points (used by the parity tests) ---- */
+
+/* hit_scene (c/main.c:239-256) for n_rays independent rays (host pointers,
+ * 6 floats each: origin, direction) against the uploaded scene. */
+int rt_debug_closest_hit(rt_ctx *ctx, const float *rays, size_t n_rays,
+                         float tmin, float tmax, int32_t *index, float *t);
+/* first n uniforms of the counter stream of (seed, pixel, sample) as the
+ * device computes them (host pointer, doubles) */
+int rt_debug_uniforms(rt_ctx *ctx, uint32_t seed, uint32_t pixel,
+                      uint32_t sample, size_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,214 @@
+"""raytrace_amd -- MI355X path-tracing kernel for the per-pixel loop of the
+inrick/raytrace C renderer, behind the C ABI of include/rt_amd.h.
+
+This Python layer is plumbing for tests and benchmarks: it mirrors the
+reference's host-side names (camera_new, small_scene, random_scene,
+raytrace) and hands numpy arrays or torch device pointers to the C ABI.  The
+product is the native code under csrc/ and host/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from ._native import (DIELECTRIC, KERNEL_MEGA, KERNEL_WAVEFRONT, MATTE, METAL, SCENE_DENSE, SCENE_FINAL, SCENE_GLASS,
+                      SCENE_SMALL, SCENE_TRIVIAL, SPHERE_DTYPE, RtCamera, RtError, RtJob)
+
+__all__ = ["camera_new", "camera_default", "small_scene", "trivial_scene", "random_scene", "glass_scene",
+           "build_scene", "Job", "Renderer", "raytrace", "write_ppm", "device_count", "RtError", "SPHERE_DTYPE"]
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def camera_new(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist):
+    """camera_new of c/structs.c:49-79."""
+    cam = RtCamera()
+    N.host.rth_camera_new(_f3(lookfrom), _f3(lookat), _f3(vup), vfov, aspect, aperture, focus_dist, C.byref(cam))
+    return cam
+
+
+def camera_default(nx, ny):
+    """The view of c/main.c:490-497 for an nx-by-ny image."""
+    cam = RtCamera()
+    N.host.rth_camera_default(nx, ny, C.byref(cam))
+    return cam
+
+
+def _two_pass(fn, *extra):
+    n = fn(None, 0, *extra)
+    s = np.zeros(n, SPHERE_DTYPE)
+    got = fn(s.ctypes.data, n, *extra)
+    if got == 0:
+        raise RuntimeError("scene builder failed")
+    return s[:got].copy()
+
+
+def small_scene():
+    return _two_pass(N.host.rth_scene_small)
+
+
+def trivial_scene():
+    return _two_pass(N.host.rth_scene_trivial)
+
+
+def _fresh_rng():
+    g = N.RthRng()
+    N.host.rth_rng_init(C.byref(g))
+    return g
+
+
+def random_scene(half_extent=11):
+    """random_scene of c/main.c:286-344 (488 spheres at half_extent 11; 40,004 at 100)."""
+    n = N.host.rth_scene_random(None, 0, half_extent, None)
+    s = np.zeros(n, SPHERE_DTYPE)
+    g = _fresh_rng()
+    got = N.host.rth_scene_random(s.ctypes.data, n, half_extent, C.byref(g))
+    return s[:got].copy()
+
+
+def glass_scene(half_extent=11):
+    n = N.host.rth_scene_glass(None, 0, half_extent, None)
+    s = np.zeros(n, SPHERE_DTYPE)
+    g = _fresh_rng()
+    got = N.host.rth_scene_glass(s.ctypes.data, n, half_extent, C.byref(g))
+    return s[:got].copy()
+
+
+def build_scene(which):
+    return {SCENE_SMALL: small_scene, SCENE_FINAL: random_scene, SCENE_DENSE: lambda: random_scene(100),
+            SCENE_GLASS: glass_scene, SCENE_TRIVIAL: trivial_scene}[which]()
+
+
+def device_count():
+    n = C.c_int()
+    N.check(N.device.rt_device_count(C.byref(n)), "rt_device_count")
+    return n.value
+
+
+def Job(nx, ny, nsamples, max_depth=50, seed=0, row0=0, tile_rows=None, tile_stride=None, n_tiles=1,
+        kernel=KERNEL_MEGA, tmin=np.float32(0.001)):
+    tile_rows = (ny - row0) if tile_rows is None else tile_rows
+    tile_stride = tile_rows if tile_stride is None else tile_stride
+    return RtJob(nx, ny, row0, tile_rows, tile_stride, n_tiles, nsamples, max_depth, float(tmin), seed, kernel, 0)
+
+
+def job_rows(job):
+    return int(N.device.rt_job_rows(C.byref(job)))
+
+
+def interleaved_job(nx, ny, nsamples, rank, world, tile_rows=8, **kw):
+    """The row tiles rank `rank` of `world` renders: tiles rank, rank+world, ..."""
+    total = (ny + tile_rows - 1) // tile_rows
+    mine = (total - rank + world - 1) // world if total > rank else 0
+    return Job(nx, ny, nsamples, row0=rank * tile_rows, tile_rows=tile_rows, tile_stride=world * tile_rows,
+               n_tiles=mine, **kw)
+
+
+def job_row_indices(job):
+    """Image rows (top = 0) the job's compact output holds, in order."""
+    rows = []
+    for t in range(job.n_tiles):
+        first = job.row0 + t * job.tile_stride
+        if first >= job.ny:
+            break
+        rows.extend(range(first, min(first + job.tile_rows, job.ny)))
+    return np.asarray(rows, dtype=np.int64)
+
+
+class Renderer:
+    """One rt_ctx: the stand-in for one render thread of c/main.c:531-539."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        N.check(N.device.rt_ctx_create(device, C.byref(h)), "rt_ctx_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            N.device.rt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        N.check(N.device.rt_ctx_set_stream(self._h, C.c_void_p(hip_stream)), "rt_ctx_set_stream")
+
+    def synchronize(self):
+        N.check(N.device.rt_ctx_synchronize(self._h), "rt_ctx_synchronize")
+
+    def upload(self, spheres):
+        s = np.ascontiguousarray(spheres)
+        assert s.dtype == SPHERE_DTYPE
+        N.check(N.device.rt_scene_upload(self._h, s.ctypes.data, len(s)), "rt_scene_upload")
+
+    def render_host(self, cam, job, debug=True):
+        """render() of c/main.c:446-483 for the job's rows -> numpy arrays."""
+        rows, nx = job_rows(job), job.nx
+        rgb = np.zeros((rows, nx, 3), np.uint8)
+        lin = np.zeros((rows, nx, 3), np.float32) if debug else None
+        fh = np.zeros((rows, nx), np.int32) if debug else None
+        hs = np.zeros((rows, nx), np.uint32) if debug else None
+        p = lambda a: None if a is None else a.ctypes.data
+        N.check(N.device.rt_render_host(self._h, C.byref(cam), C.byref(job), p(rgb), p(lin), p(fh), p(hs)),
+                "rt_render_host")
+        return {"rgb8": rgb, "linear": lin, "first_hit": fh, "hit_sum": hs}
+
+    def render_device(self, cam, job, d_rgb8, d_linear=0, d_first_hit=0, d_hit_sum=0):
+        """Asynchronous render into device pointers (ints, e.g. tensor.data_ptr())."""
+        N.check(N.device.rt_render_device(self._h, C.byref(cam), C.byref(job), C.c_void_p(d_rgb8),
+                                          C.c_void_p(d_linear or None), C.c_void_p(d_first_hit or None),
+                                          C.c_void_p(d_hit_sum or None)), "rt_render_device")
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        N.check(N.device.rt_ctx_last_kernel_ms(self._h, C.byref(ms)), "rt_ctx_last_kernel_ms")
+        return ms.value
+
+    def counters(self, reset=False):
+        c = N.RtCounters()
+        N.check(N.device.rt_ctx_counters(self._h, C.byref(c), int(reset)), "rt_ctx_counters")
+        return c.as_dict()
+
+    def closest_hit(self, rays, tmin=np.float32(0.001), tmax=np.finfo(np.float32).max):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        idx = np.zeros(len(rays), np.int32)
+        t = np.zeros(len(rays), np.float32)
+        N.check(N.device.rt_debug_closest_hit(self._h, rays.ctypes.data, len(rays), float(tmin), float(tmax),
+                                              idx.ctypes.data, t.ctypes.data), "rt_debug_closest_hit")
+        return idx, t
+
+    def uniforms(self, seed, pixel, sample, n):
+        out = np.zeros(n, np.float64)
+        N.check(N.device.rt_debug_uniforms(self._h, seed, pixel, sample, n, out.ctypes.data), "rt_debug_uniforms")
+        return out
+
+
+def raytrace(cam, spheres, nx, ny, nsamples, n_devices=1, max_depth=50, seed=0, tile_rows=8, kernel=KERNEL_MEGA,
+             device_ids=None):
+    """raytrace() of c/main.c:485-548 through the C driver: row tiles over
+    n_devices GPUs, gathered on the host.  Returns (image, max kernel ms)."""
+    s = np.ascontiguousarray(spheres)
+    img = np.zeros((ny, nx, 3), np.uint8)
+    ids = None
+    if device_ids is not None:
+        ids = (C.c_int * len(device_ids))(*device_ids)
+    opts = N.RthRenderOpts(nx, ny, nsamples, max_depth, seed, tile_rows, kernel, n_devices, ids)
+    ms = C.c_float()
+    N.check(N.host.rth_raytrace(C.byref(cam), s.ctypes.data, len(s), C.byref(opts), img.ctypes.data, C.byref(ms)),
+            "rth_raytrace")
+    return img, ms.value
+
+
+def write_ppm(path, img):
+    """ppm_write of c/main.c:410-415 (the bytes, written from Python)."""
+    h, w, _ = img.shape
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d 255\n" % (w, h))
+        f.write(np.ascontiguousarray(img).tobytes())

@@ -1,0 +1,307 @@
+// rt_core.h -- per-lane arithmetic of the path tracer, written once for the
+// HIP kernels.  Every function is __host__ __device__ so that the unit tests
+// can also run the very same source on the CPU and compare it bit for bit
+// with the oracle; the product library only ever runs it on the GPU.
+//
+// Rounding contract: this file is compiled with -ffp-contract=off.  A plain
+// `a*b + c` is two roundings, as in the reference built the same way; every
+// fused multiply-add is spelled rt_fma().  float division and square root are
+// the correctly rounded ones.  Where C's promotion rules make a reference
+// expression a double expression, it is a double expression here too; each
+// such place cites its line.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rtcore {
+
+constexpr float kFltEpsilon = 1.1920928955078125e-07f;
+constexpr float kFltMax = 3.4028234663852886e+38f;
+
+RT_HD float rt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+struct V3 {
+  float x, y, z;
+};
+
+RT_HD V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RT_HD V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_HD V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_HD V3 operator*(float k, V3 a) { return V3{k * a.x, k * a.y, k * a.z}; }
+RT_HD V3 operator/(V3 a, float k) { return V3{a.x / k, a.y / k, a.z / k}; }
+RT_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+// c/vec.c:48-50
+RT_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// c/vec.c:37-39
+RT_HD float length(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+// c/vec.c:41-46: reciprocal as a double divide narrowed to float
+RT_HD V3 normalize(V3 a) {
+  float k = (float)(1.0 / (double)length(a));
+  return k * a;
+}
+// c/vec.c:60-62
+RT_HD V3 reflect(V3 u, V3 n) {
+  float k = 2.0f * dot(u, n);
+  return u - k * n;
+}
+
+// ---------------------------------------------------------------- generator
+//
+// Counter generator: draw k of path (seed, pixel, sample) is
+// mix32(key + k*0x9e3779b9) >> 1, a 31-bit integer r, returned as the double
+// r / 2147483647 exactly as c/rand.c:15 converts its integer.
+
+RT_HD uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+RT_HD uint32_t path_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+  uint32_t a = mix32(pixel + 0x9e3779b9u * seed);
+  return mix32(a ^ (sample * 0x85ebca6bu + 0x165667b1u));
+}
+
+// r / (2^31 - 1) correctly rounded to double without a division:
+// r/(2^31-1) = r*2^-31 * (1 + 2^-31 + 2^-62 + ...).  x = r*2^-31 is exact; one
+// fused multiply-add x*(2^-31 + 2^-62) + x rounds a value that differs from
+// the quotient by less than x*2^-92, far inside the gap a 31-bit r leaves
+// around any rounding boundary.  tests/test_rng_exhaustive checks all 2^31
+// values against the division.
+RT_HD double unit_from_bits(uint32_t r31) {
+  double x = (double)r31 * 4.656612873077392578125e-10;  // 2^-31
+  const double tail = 4.656612873077392578125e-10 + 2.1684043449710088680149056017398834228515625e-19;
+  return __builtin_fma(x, tail, x);
+}
+
+struct Rng {
+  uint32_t key;
+  uint32_t k;
+};
+
+RT_HD double next_uniform(Rng &g) {
+  uint32_t r = mix32(g.key + g.k * 0x9e3779b9u) >> 1;
+  g.k++;
+  return unit_from_bits(r);
+}
+
+// c/vec.c:64-72
+RT_HD V3 unit_ball(Rng &g) {
+  for (;;) {
+    float ux = (float)next_uniform(g);
+    float uy = (float)next_uniform(g);
+    float uz = (float)next_uniform(g);
+    V3 u = 2.0f * v3(ux, uy, uz) - v3(1.0f, 1.0f, 1.0f);
+    float len = length(u);
+    if (len < 1.0f && !(__builtin_fabsf(len) < kFltEpsilon)) return u;
+  }
+}
+
+// ------------------------------------------------------------------ camera
+
+struct Camera {  // same layout as rt_camera
+  V3 llc, horiz, vert, origin, u, v, w;
+  float lens_radius;
+};
+
+// c/structs.c:81-92
+RT_HD void camera_ray(const Camera &c, float x, float y, Rng &g, V3 &A, V3 &B) {
+  V3 rd = c.lens_radius * unit_ball(g);
+  V3 off = rd.x * c.u + rd.y * c.v;
+  V3 on_plane = c.llc + (x * c.horiz + y * c.vert);
+  B = (on_plane - c.origin) - off;
+  A = c.origin + off;
+}
+
+// pixel -> (x, y) of c/main.c:465-466 with one band (ymin 0, ymax 1);
+// `up` = rows below this one = the reference's j-1
+RT_HD void pixel_xy(uint32_t col, uint32_t up, uint32_t nx, uint32_t ny, Rng &g, float &x, float &y) {
+  x = (float)((double)col + next_uniform(g)) / (float)nx;
+  y = (float)((double)up + next_uniform(g)) / (float)ny;
+}
+
+// ------------------------------------------------------- conservative filter
+//
+// The scan does not evaluate the reference's discriminant for every sphere.
+// It evaluates a cheaper quantity Df with fused arithmetic in expanded form,
+//   b  = A.B - C.B
+//   c0 = (|C|^2 - r^2)' - 2 A.C            (' = lowered by the margin below)
+//   Df = b*b - a*(|A|^2)(1-kappa) - a*c0
+// such that  D_reference > 0  implies  Df > 0  (no false negatives), and runs
+// the reference's exact arithmetic only for the spheres that pass.  The
+// margin kappa*a*(|A|^2 + |C|^2 + r^2) with kappa = 2^-17 = 128 u covers both
+// the rounding of this expansion (< 24 u a (M^2 + r^2), M = |A|+|C|) and the
+// rounding of the reference's own discriminant (< 20 u a (|A-C|^2 + r^2)),
+// using M^2 <= 2(|A|^2+|C|^2) and u = 2^-24.
+
+constexpr double kFilterKappa = 1.0 / 131072.0;  // 2^-17
+
+struct FilterSphere {  // one LDS entry, 16 B
+  float cx, cy, cz, kprime;
+};
+
+// host side only, at scene upload (double arithmetic, result rounded down)
+inline FilterSphere make_filter_sphere(float cx, float cy, float cz, float r) {
+  double cc = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+  double rr = (double)r * r;
+  double k = cc - rr - kFilterKappa * (cc + rr);
+  float kf = (float)k;
+  if ((double)kf > k) kf = __builtin_nextafterf(kf, -kFltMax);
+  return FilterSphere{cx, cy, cz, kf};
+}
+
+struct FilterRay {  // per segment, per lane
+  float nbx, nby, nbz;  // -B
+  float ab;             // A.B
+  float m2ax, m2ay, m2az;  // -2A
+  float na;             // -(B.B)
+  float naaa;           // -(B.B)(A.A)(1-kappa), rounded up in magnitude-safe direction
+};
+
+RT_HD FilterRay make_filter_ray(V3 A, V3 B) {
+  double a = (double)B.x * B.x + (double)B.y * B.y + (double)B.z * B.z;
+  double aa = (double)A.x * A.x + (double)A.y * A.y + (double)A.z * A.z;
+  double ab = (double)A.x * B.x + (double)A.y * B.y + (double)A.z * B.z;
+  FilterRay f;
+  f.nbx = -B.x; f.nby = -B.y; f.nbz = -B.z;
+  f.m2ax = -2.0f * A.x; f.m2ay = -2.0f * A.y; f.m2az = -2.0f * A.z;
+  f.ab = (float)ab;
+  f.na = -(float)a;
+  f.naaa = (float)(-(a * aa) * (1.0 - kFilterKappa));
+  return f;
+}
+
+// eight fused multiply-adds per ray-sphere pair
+RT_HD float filter_discriminant(const FilterRay &f, float cx, float cy, float cz, float kprime) {
+  float b = rt_fma(f.nbx, cx, rt_fma(f.nby, cy, rt_fma(f.nbz, cz, f.ab)));
+  float c0 = rt_fma(f.m2ax, cx, rt_fma(f.m2ay, cy, rt_fma(f.m2az, cz, kprime)));
+  return rt_fma(f.na, c0, rt_fma(b, b, f.naaa));
+}
+
+// ------------------------------------------------------------ exact hit test
+
+// c/main.c:214-236 for one sphere.  r2 = radius*radius (a float product, as
+// the reference forms it).  On a hit inside (tmin, tmax) returns true and t.
+RT_HD bool exact_hit(V3 A, V3 B, float a, float cx, float cy, float cz, float r2, float tmin, float tmax, float &t) {
+  V3 oc = A - v3(cx, cy, cz);
+  float b = dot(oc, B);
+  float c = dot(oc, oc) - r2;
+  float D = b * b - a * c;
+  if (D > 0.0f) {
+    double root = __builtin_sqrt((double)D);
+    double nb = (double)(-b), da = (double)a;
+    float t0 = (float)((nb - root) / da);
+    if (tmin < t0 && t0 < tmax) { t = t0; return true; }
+    float t1 = (float)((nb + root) / da);
+    if (tmin < t1 && t1 < tmax) { t = t1; return true; }
+  }
+  return false;
+}
+
+// --------------------------------------------------------------- materials
+
+// c/main.c:140-144.  (1-cosine)^5 by three double products instead of libm
+// pow: agrees with it to a few units of the last double place, which the
+// narrowing to float hides except about once in 2^27 calls.
+RT_HD float schlick(float cosine, float ref_idx) {
+  float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+  r0 = r0 * r0;
+  double x = (double)(1.0f - cosine);
+  double x2 = x * x;
+  double x5 = x2 * x2 * x;
+  return (float)((double)r0 + (double)(1.0f - r0) * x5);
+}
+
+// c/main.c:146-158
+RT_HD bool refract(V3 u, V3 n, float ni_over_nt, V3 &out) {
+  V3 un = normalize(u);
+  float dt = dot(un, n);
+  float D = (float)(1.0 - (double)(ni_over_nt * ni_over_nt * (1.0f - dt * dt)));
+  if (D > 0.0f) {
+    float rootD = __builtin_sqrtf(D);
+    out = ni_over_nt * (un - dt * n) - rootD * n;
+    return true;
+  }
+  return false;
+}
+
+struct Material {
+  int type;
+  V3 albedo;
+  float param;
+};
+
+// c/main.c:163-211.  p, n: hit point and normal.  Returns false for an
+// absorbed metal ray (c/main.c:179); otherwise atten and the new ray.
+RT_HD bool scatter(const Material &m, V3 A, V3 B, V3 p, V3 n, Rng &g, V3 &atten, V3 &oA, V3 &oB) {
+  (void)A;
+  oA = p;
+  if (m.type == 0) {  // matte, c/main.c:168-173
+    V3 target = (p + n) + unit_ball(g);
+    atten = m.albedo;
+    oB = target - p;
+    return true;
+  }
+  if (m.type == 1) {  // metal, c/main.c:174-180
+    V3 mirrored = reflect(normalize(B), n);
+    V3 dir = mirrored + m.param * unit_ball(g);
+    atten = m.albedo;
+    oB = dir;
+    return dot(dir, n) > 0.0f;
+  }
+  // dielectric, c/main.c:181-206
+  float idx = m.param;
+  float bn = dot(B, n);
+  V3 outward;
+  float ni_over_nt, cosine;
+  if (bn > 0.0f) {
+    outward = -n;
+    ni_over_nt = idx;
+    cosine = idx * bn / length(B);
+  } else {
+    outward = n;
+    ni_over_nt = (float)(1.0 / (double)idx);
+    cosine = -bn / length(B);
+  }
+  V3 bent;
+  bool go_through = false;
+  if (refract(B, outward, ni_over_nt, bent)) {
+    go_through = next_uniform(g) >= (double)schlick(cosine, idx);
+  }
+  oB = go_through ? bent : reflect(B, n);
+  atten = v3(1.0f, 1.0f, 1.0f);
+  return true;
+}
+
+// sky of c/main.c:274-278
+RT_HD V3 sky(V3 B) {
+  float t = (float)(0.5 * ((double)normalize(B).y + 1.0));
+  float k = (float)(1.0 - (double)t);
+  V3 white = k * v3(1.0f, 1.0f, 1.0f);
+  V3 blue = t * v3(0.75f, (float)0.95, 1.0f);
+  return white + blue;
+}
+
+// c/main.c:470-477: mean, square root, NaN scrub, truncation to 8 bits
+RT_HD void finish_pixel(V3 sum, uint32_t nsamples, V3 &mean, uint8_t rgb[3]) {
+  mean = sum / (float)nsamples;
+  V3 c = v3(__builtin_sqrtf(mean.x), __builtin_sqrtf(mean.y), __builtin_sqrtf(mean.z));
+  if (c.x != c.x) c.x = 0.0f;
+  if (c.y != c.y) c.y = 0.0f;
+  if (c.z != c.z) c.z = 0.0f;
+  rgb[0] = (uint8_t)(int)(255.0f * c.x);
+  rgb[1] = (uint8_t)(int)(255.0f * c.y);
+  rgb[2] = (uint8_t)(int)(255.0f * c.z);
+}
+
+}  // namespace rtcore

@@ -1,0 +1,70 @@
+/*
+ * rt_host.h -- host side of the renderer, plain C: the scene builders, the
+ * camera set-up, the multi-GPU driver and the PPM writer.  It is what stays
+ * on the CPU of the reference's c/main.c and c/structs.c; everything per
+ * pixel goes through the C ABI of include/rt_amd.h.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/rt_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the reference's generator (c/rand.c:3-16) with the seed made explicit;
+ * only the scene builders use it */
+typedef struct { uint32_t state; } rth_rng;
+void rth_rng_init(rth_rng *g);                 /* state = 123456789 (c/rand.c:9) */
+uint32_t rth_rng_hash(uint32_t index);
+double rth_rng_next(rth_rng *g);
+
+/* camera_new, c/structs.c:49-79 */
+void rth_camera_new(const float lookfrom[3], const float lookat[3], const float vup[3], float vfov, float aspect,
+                    float aperture, float focus_dist, rt_camera *out);
+/* the view raytrace() sets up, c/main.c:490-497, for an nx-by-ny image */
+void rth_camera_default(uint32_t nx, uint32_t ny, rt_camera *out);
+
+/* Scene builders.  Each returns the sphere count; called with out == NULL it
+ * returns the count needed (the protocol of small_scene, c/main.c:366-372). */
+size_t rth_scene_small(rt_sphere *out, size_t cap);                 /* c/main.c:369-408 */
+size_t rth_scene_trivial(rt_sphere *out, size_t cap);               /* c/main.c:348-363 */
+/* random_scene, c/main.c:286-344, on a (2*half_extent)^2 grid; the reference
+ * has half_extent 11 (488 spheres); 100 gives the 40,004-sphere field */
+size_t rth_scene_random(rt_sphere *out, size_t cap, int half_extent, rth_rng *g);
+/* stress scene: random_scene's geometry, matte -> glass 1.5, metal -> mirror */
+size_t rth_scene_glass(rt_sphere *out, size_t cap, int half_extent, rth_rng *g);
+
+enum { RTH_SCENE_SMALL = 0, RTH_SCENE_FINAL = 1, RTH_SCENE_DENSE = 2, RTH_SCENE_GLASS = 3, RTH_SCENE_TRIVIAL = 4 };
+/* allocates with malloc; caller frees */
+int rth_scene_build(int which, rt_sphere **out, size_t *n);
+
+/* ppm_write, c/main.c:410-415 */
+int rth_write_ppm(FILE *fp, const uint8_t *rgb8, size_t w, size_t h);
+
+/* raytrace(), c/main.c:485-548, with GPUs in place of threads: row tiles of
+ * tile_rows rows are dealt round-robin over n_devices contexts (one host
+ * thread each), every device renders its tiles in one launch, and the tiles
+ * are copied into their places in rgb8 (3*nx*ny bytes, caller's).  Because
+ * the generator is keyed by (pixel, sample) the image does not depend on
+ * n_devices or tile_rows.  device_ids may be NULL (0..n_devices-1, wrapped
+ * onto the devices present).  kernel_ms_max, if not NULL, receives the
+ * longest per-device kernel time. */
+typedef struct {
+  uint32_t nx, ny, nsamples, max_depth, seed, tile_rows, kernel;
+  int n_devices;
+  const int *device_ids;
+} rth_render_opts;
+
+int rth_raytrace(const rt_camera *cam, const rt_sphere *spheres, size_t n, const rth_render_opts *opts, uint8_t *rgb8,
+                 float *kernel_ms_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,154 @@
+// core_host.cpp -- TEST HARNESS ONLY.  Compiles raytrace_amd/csrc/rt_core.h
+// (the per-lane arithmetic the HIP kernels are built from) for the host, so
+// that CPU-only tests can check that source bit for bit against the oracle:
+// the filter's no-false-negative property, the exact hit test, the scatter
+// functions, the generator and a per-pixel walk with the kernel's control
+// flow.  The product library never runs this; there is no CPU render path.
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "../../raytrace_amd/csrc/rt_core.h"
+
+using namespace rtcore;
+
+extern "C" {
+
+void core_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, size_t n, double *out) {
+  Rng g{path_key(seed, pixel, sample), 0};
+  for (size_t i = 0; i < n; i++) out[i] = next_uniform(g);
+}
+
+// For every (ray, sphere) pair: reference discriminant sign vs filter sign.
+// Returns the number of pairs with D_ref > 0 but filter <= 0 (must be 0);
+// *passed = pairs the filter lets through, *ref_pos = pairs with D_ref > 0.
+uint64_t core_filter_check(const rt_sphere *s, size_t n, const float *rays, size_t n_rays, uint64_t *passed,
+                           uint64_t *ref_pos) {
+  std::vector<FilterSphere> fs(n);
+  for (size_t i = 0; i < n; i++) fs[i] = make_filter_sphere(s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius);
+  uint64_t bad = 0, pass = 0, pos = 0;
+  for (size_t r = 0; r < n_rays; r++) {
+    V3 A = v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]);
+    V3 B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
+    FilterRay fr = make_filter_ray(A, B);
+    float a = dot(B, B);
+    for (size_t i = 0; i < n; i++) {
+      V3 oc = A - v3(s[i].center[0], s[i].center[1], s[i].center[2]);
+      float b = dot(oc, B);
+      float c = dot(oc, oc) - s[i].radius * s[i].radius;
+      float D = b * b - a * c;
+      float Df = filter_discriminant(fr, fs[i].cx, fs[i].cy, fs[i].cz, fs[i].kprime);
+      if (Df > 0.0f) pass++;
+      if (D > 0.0f) {
+        pos++;
+        if (!(Df > 0.0f)) bad++;
+      }
+    }
+  }
+  if (passed) *passed = pass;
+  if (ref_pos) *ref_pos = pos;
+  return bad;
+}
+
+static int closest(const rt_sphere *s, const FilterSphere *fs, size_t n, V3 A, V3 B, float tmin, float tmax,
+                   float &t_out, uint64_t *cand) {
+  FilterRay fr = make_filter_ray(A, B);
+  float a = dot(B, B);
+  float best = tmax;
+  int idx = -1;
+  for (size_t i = 0; i < n; i++) {
+    if (filter_discriminant(fr, fs[i].cx, fs[i].cy, fs[i].cz, fs[i].kprime) > 0.0f) {
+      if (cand) (*cand)++;
+      float t;
+      if (exact_hit(A, B, a, s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius * s[i].radius, tmin, best, t)) {
+        best = t;
+        idx = (int)i;
+      }
+    }
+  }
+  t_out = best;
+  return idx;
+}
+
+void core_closest_hit(const rt_sphere *s, size_t n, const float *rays, size_t n_rays, float tmin, float tmax,
+                      int32_t *index, float *t) {
+  std::vector<FilterSphere> fs(n);
+  for (size_t i = 0; i < n; i++) fs[i] = make_filter_sphere(s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius);
+  for (size_t r = 0; r < n_rays; r++) {
+    V3 A = v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]);
+    V3 B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
+    float tt;
+    index[r] = closest(s, fs.data(), n, A, B, tmin, tmax, tt, nullptr);
+    t[r] = index[r] >= 0 ? tt : 0.0f;
+  }
+}
+
+// The kernel's per-lane walk (mega_kernel of rt_device.hip) for the pixels of
+// rows [row0, row0+rows): same functions, same order.
+void core_render(const rt_camera *cam_in, const rt_sphere *s, size_t n, uint32_t nx, uint32_t ny, uint32_t row0,
+                 uint32_t rows, uint32_t nsamples, uint32_t max_depth, float tmin, uint32_t seed, uint8_t *rgb8,
+                 float *linear, int32_t *first_hit, uint32_t *hit_sum, uint64_t *stats /* paths, segments, cand */) {
+  Camera cam;
+  static_assert(sizeof(Camera) == sizeof(rt_camera), "layout");
+  std::memcpy(&cam, cam_in, sizeof cam);
+  std::vector<FilterSphere> fs(n);
+  for (size_t i = 0; i < n; i++) fs[i] = make_filter_sphere(s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius);
+  uint64_t paths = 0, segs = 0, cands = 0;
+  for (uint32_t row = row0; row < row0 + rows; row++) {
+    for (uint32_t col = 0; col < nx; col++) {
+      uint32_t pixel = row * nx + col, up = ny - 1 - row;
+      V3 sum = v3(0, 0, 0);
+      int32_t fh0 = -1;
+      uint32_t hsum = 0;
+      for (uint32_t sample = 0; sample < nsamples; sample++) {
+        Rng g{path_key(seed, pixel, sample), 0};
+        float x, y;
+        pixel_xy(col, up, nx, ny, g, x, y);
+        V3 A, B;
+        camera_ray(cam, x, y, g, A, B);
+        V3 color = v3(1, 1, 1);
+        for (uint32_t depth = 0;;) {
+          float t;
+          segs++;
+          int idx = closest(s, fs.data(), n, A, B, tmin, kFltMax, t, &cands);
+          if (depth == 0) {
+            hsum += (uint32_t)(idx + 1);
+            if (sample == 0) fh0 = idx;
+          }
+          if (idx < 0) {
+            color = color * sky(B);
+            break;
+          }
+          V3 ctr = v3(s[idx].center[0], s[idx].center[1], s[idx].center[2]);
+          V3 p = A + t * B;
+          V3 nrm = (p - ctr) / s[idx].radius;
+          Material m{s[idx].type, v3(s[idx].albedo[0], s[idx].albedo[1], s[idx].albedo[2]), s[idx].param};
+          V3 atten, nA, nB;
+          if (!scatter(m, A, B, p, nrm, g, atten, nA, nB)) {
+            color = v3(0, 0, 0);
+            break;
+          }
+          A = nA;
+          B = nB;
+          color = atten * color;
+          if (++depth >= max_depth) break;
+        }
+        sum = sum + color;
+        paths++;
+      }
+      size_t o = (size_t)(row - row0) * nx + col;
+      V3 mean;
+      uint8_t px[3];
+      finish_pixel(sum, nsamples, mean, px);
+      if (rgb8) std::memcpy(rgb8 + 3 * o, px, 3);
+      if (linear) { linear[3 * o] = mean.x; linear[3 * o + 1] = mean.y; linear[3 * o + 2] = mean.z; }
+      if (first_hit) first_hit[o] = fh0;
+      if (hit_sum) hit_sum[o] = hsum;
+    }
+  }
+  if (stats) { stats[0] = paths; stats[1] = segs; stats[2] = cands; }
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+"""The kernels' per-lane arithmetic (raytrace_amd/csrc/rt_core.h) compiled for
+the host by the test harness and checked against the oracle on the CPU: the
+filter never drops a sphere the reference would hit, the filtered scan gives
+the reference's closest hit, and the kernel's per-pixel walk is bit-identical
+to the oracle.  CPU only; the product never runs this path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import as_oracle_scene, random_rays
+
+
+def vp(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def test_generator_matches_oracle(core, oracle):
+    out = np.zeros(4096, np.float64)
+    for seed, pixel, sample in ((0, 0, 0), (7, 123456, 63), (0xFFFFFFFF, 8294399, 1023)):
+        core.core_uniforms(seed, pixel, sample, C.c_size_t(len(out)), vp(out))
+        key = oracle.lib.orc_path_key(seed, pixel, sample)
+        want = np.array([oracle.lib.orc_ctr_uniform(key, k) for k in range(len(out))])
+        assert np.array_equal(out.view(np.uint64), want.view(np.uint64))
+
+
+def adversarial_rays(rng, spheres, n):
+    """Tangent and near-tangent rays, rays leaving a surface, huge and tiny directions."""
+    idx = rng.integers(0, len(spheres), n)
+    c, r = spheres["center"][idx].astype(np.float64), spheres["radius"][idx].astype(np.float64)
+    A = rng.uniform(-15, 15, (n, 3))
+    A[:, 1] = rng.uniform(0, 4, n)
+    to_c = c - A
+    dist = np.linalg.norm(to_c, axis=1)
+    w = to_c / dist[:, None]
+    t1 = np.cross(w, rng.normal(size=(n, 3)))
+    t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    # aim at a point displaced r*(1+eps) sideways from the centre: grazing by construction
+    eps = rng.choice([0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3], n)
+    target = c + t1 * (r * (1 + eps))[:, None]
+    B = (target - A) * rng.choice([0.01, 1, 1, 40], n)[:, None]
+    return np.concatenate([A, B], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("builder", ["small_scene", "random_scene", "dense"])
+def test_filter_has_no_false_negatives(core, rt, builder):
+    sc = rt.random_scene(100)[::9][:3000] if builder == "dense" else getattr(rt, builder)()
+    rng = np.random.default_rng(3)
+    rays = np.concatenate([random_rays(rng, 3000, sc), adversarial_rays(rng, sc, 6000)])
+    passed, pos = C.c_uint64(), C.c_uint64()
+    core.core_filter_check.restype = C.c_uint64
+    bad = core.core_filter_check(vp(sc), C.c_size_t(len(sc)), vp(rays), C.c_size_t(len(rays)), C.byref(passed), C.byref(pos))
+    assert bad == 0
+    assert pos.value > 5000                       # the reference discriminant was positive often ...
+    assert passed.value < 1.35 * pos.value + 3 * len(rays)   # ... and the filter is not much looser
+
+
+def test_filtered_scan_equals_reference_scan(core, rt, oracle):
+    rng = np.random.default_rng(4)
+    for sc in (rt.small_scene(), rt.random_scene(), rt.glass_scene()):
+        rays = np.concatenate([random_rays(rng, 1500, sc), adversarial_rays(rng, sc, 1500)])
+        idx = np.zeros(len(rays), np.int32)
+        t = np.zeros(len(rays), np.float32)
+        core.core_closest_hit(vp(sc), C.c_size_t(len(sc)), vp(rays), C.c_size_t(len(rays)), C.c_float(0.001),
+                              C.c_float(np.finfo(np.float32).max), vp(idx), vp(t))
+        osc = as_oracle_scene(sc)
+        for i, r in enumerate(rays):
+            oi, ot, _, _ = oracle.hit_scene(osc, r[:3], r[3:])
+            assert oi == idx[i]
+            if oi >= 0:
+                assert ot.tobytes() == t[i].tobytes()
+
+
+@pytest.mark.parametrize("scene,nx,ny,spp", [("small_scene", 96, 54, 4), ("random_scene", 96, 54, 4), ("glass_scene", 64, 36, 8)])
+def test_kernel_walk_is_bit_identical_to_oracle(core, rt, oracle, scene, nx, ny, spp):
+    sc = getattr(rt, scene)()
+    cam = rt.camera_default(nx, ny)
+    rgb = np.zeros((ny, nx, 3), np.uint8)
+    lin = np.zeros((ny, nx, 3), np.float32)
+    fh = np.zeros((ny, nx), np.int32)
+    hs = np.zeros((ny, nx), np.uint32)
+    st = np.zeros(3, np.uint64)
+    core.core_render(C.byref(cam), vp(sc), C.c_size_t(len(sc)), nx, ny, 0, ny, spp, 50, C.c_float(np.float32(0.001)), 5,
+                     vp(rgb), vp(lin), vp(fh), vp(hs), vp(st))
+    o = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=5)
+    assert np.array_equal(rgb, o["rgb8"])
+    assert np.array_equal(lin.view(np.uint32), o["linear"].view(np.uint32))
+    assert np.array_equal(fh, o["first_hit"]) and np.array_equal(hs, o["hit_sum"])
+    assert st[0] == nx * ny * spp and st[1] <= o["stats"]["segments"]   # absorbed paths end early here
