@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- camera paths/s of the per-pixel path-tracing loop on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A step is one render of the workload's frame.  N = 1: the final scene (488
+spheres) at 1920x1080, 64 spp, max depth 50 (BASELINE config 1).  N > 1
+(launched by torch.distributed.run, one rank per GPU): the same frame at 64*N
+spp, its 8-row tiles dealt round-robin to the ranks, every rank's tiles
+gathered to rank 0 each step (the only communication) -- weak scaling, the
+same number of paths per GPU.  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3      # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+FLOP_PER_TEST = 17            # one ray-sphere discriminant, a and r^2 hoisted (3 sub, 5, 6, 3)
+
+WORKLOADS = {
+    # name: (scene builder name, half_extent, nx, ny, spp, max_depth)
+    "final1080": ("random_scene", 11, 1920, 1080, 64, 50),
+    "final4k": ("random_scene", 11, 3840, 2160, 1024, 50),
+    "dense1080": ("random_scene", 100, 1920, 1080, 16, 50),
+    "glass1080": ("glass_scene", 11, 1920, 1080, 256, 50),
+    "small600": ("small_scene", None, 600, 300, 10, 50),
+}
+
+
+def cpu_baseline(nx, ny, scene_name, half_extent, max_depth):
+    """The oracle (the build's C restatement of the reference, byte-identical to
+    it on the goldens) timed on this host's cores on a bounded sample."""
+    from oracle import oracle as O
+    orc = O.Oracle()
+    sc = {"random_scene": lambda: orc.scene_random(half_extent or 11), "glass_scene": lambda: orc.scene_glass(half_extent or 11),
+          "small_scene": orc.scene_small}[scene_name]()
+    cores = max(1, min(16, os.cpu_count() or 1))
+    cam = orc.camera_default(nx, ny)
+    spp = 2 if len(sc) < 2000 else 1
+    rows = ny if len(sc) < 2000 else max(8, ny // 60)
+    row0 = (ny - rows) // 2
+    t0 = time.perf_counter()
+    out = orc.render_det(cam, sc, nx, ny, spp, max_depth=max_depth, seed=0, row0=row0, rows=rows, host_threads=cores,
+                         want_debug=False)
+    dt = time.perf_counter() - t0
+    paths = out["stats"]["paths"]
+    res = {"value": paths / dt, "unit": "camera paths/s", "cores": cores, "kind": "port",
+           "sample": f"{nx}x{ny} rows {row0}..{row0 + rows - 1}, {spp} spp, {paths} paths in {dt:.2f} s, "
+                     f"oracle/rt_oracle.c -O2 -ffp-contract=off, {cores} pthreads"}
+    # the reference binary itself (600x300 is hard-coded in it), when it was built
+    if scene_name == "random_scene" and (half_extent or 11) == 11 and os.path.exists(O.REF_BIN_FINAL):
+        try:
+            t0 = time.perf_counter()
+            subprocess.run([O.REF_BIN_FINAL, "-n", "10", "-t", str(cores), "-o", "-"], stdout=subprocess.DEVNULL,
+                           check=True, timeout=300)
+            dt = time.perf_counter() - t0
+            res["reference_binary"] = {"value": 600 * 300 * 10 / dt, "unit": "camera paths/s", "cores": cores,
+                                       "sample": f"reference CLI, revived random_scene, 600x300 -n 10 -t {cores}, {dt:.2f} s"}
+        except Exception as e:  # the baseline is a report, never a reason to fail the bench
+            res["reference_binary"] = {"error": str(e)}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="final1080", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--kernel", default="mega", choices=["mega", "wavefront"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import raytrace_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene_name, half_extent, nx, ny, spp, max_depth = WORKLOADS[args.workload]
+    spp = args.spp or spp
+    spp_total = spp * world                      # weak scaling: same paths per GPU
+    sc = getattr(rt, scene_name)(half_extent) if half_extent else getattr(rt, scene_name)()
+    cam = rt.camera_default(nx, ny)
+    kernel = rt.KERNEL_MEGA if args.kernel == "mega" else rt.KERNEL_WAVEFRONT
+
+    r = rt.Renderer(local_rank)
+    # a side stream of torch's: the kernels, the events that time them and the gather all run on it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    r.set_stream(stream.cuda_stream)
+    r.upload(sc)
+    tile_rows = 8
+    job = rt.interleaved_job(nx, ny, spp_total, rank, world, tile_rows, max_depth=max_depth, seed=0, kernel=kernel)
+    my_rows = rt.job_rows(job)
+    max_rows = max(rt.job_rows(rt.interleaved_job(nx, ny, spp_total, q, world, tile_rows)) for q in range(world))
+    tiles = torch.zeros((max_rows, nx, 3), dtype=torch.uint8, device=dev)       # this rank's tiles, padded
+    gathered = [torch.zeros_like(tiles) for _ in range(world)] if (world > 1 and rank == 0) else None
+    frame = torch.zeros((ny, nx, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+    row_index = [torch.as_tensor(rt.job_row_indices(rt.interleaved_job(nx, ny, spp_total, q, world, tile_rows)), device=dev)
+                 for q in range(world)] if rank == 0 else None
+
+    def step(ev=None):
+        if ev:
+            ev[0].record(stream)
+        r.render_device(cam, job, tiles.data_ptr())
+        if ev:
+            ev[1].record(stream)
+        if world > 1:
+            dist.gather(tiles, gathered, dst=0)
+            if rank == 0:
+                for q in range(world):
+                    frame[row_index[q]] = gathered[q][: len(row_index[q])]
+        else:
+            frame[row_index[0]] = tiles[:my_rows]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.counters(reset=True)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    counters = r.counters()
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    paths_per_step_rank = my_rows * nx * spp_total
+    total_paths_per_step = nx * ny * spp_total
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        tests_per_launch = counters["tests"] / args.steps
+        achieved = FLOP_PER_TEST * tests_per_launch / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "camera paths/sec (Msamples/s) final scene 1920x1080; % FP32 VALU peak",
+            "value": total_paths_per_step * args.steps / dt,
+            "unit": "camera paths/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {scene_name} {len(sc)} spheres, {nx}x{ny}, {spp_total} spp "
+                                   f"({spp} per GPU), max_depth {max_depth}, deterministic counter-RNG mode, "
+                                   f"{tile_rows}-row tiles round-robin over {world} GPU(s), gather to rank 0",
+                       "kernel": args.kernel, "paths_per_step": total_paths_per_step,
+                       "msamples_per_s": total_paths_per_step * args.steps / dt / 1e6},
+            "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "mega_kernel" if args.kernel == "mega" else "wavefront stages",
+                         "kernel_ms_avg": k_ms, "flop_per_test": FLOP_PER_TEST,
+                         "tests_per_launch": tests_per_launch,
+                         "tests_per_path": counters["tests"] / max(1, counters["paths"]),
+                         "segments_per_path": counters["segments"] / max(1, counters["paths"]),
+                         "exact_evaluations_per_segment": counters["candidates"] / max(1, counters["segments"]),
+                         "rank0_paths_per_launch": paths_per_step_rank},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx, ny, scene_name, half_extent, max_depth)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()
