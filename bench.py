@@ -156,7 +156,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     counters = r.counters()
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    launch_ms = [a.elapsed_time(b) for a, b in events]                      # trace + resolve, torch events
+    kernel_ms = [r.trace_ms(back) for back in range(args.steps)]            # trace kernel alone, the library's HIP events
     paths_per_step_rank = my_rows * nx * spp_total
     total_paths_per_step = nx * ny * spp_total
 
@@ -184,8 +185,9 @@ def main():
                        "msamples_per_s": total_paths_per_step * args.steps / dt / 1e6},
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "mega_kernel" if args.kernel == "mega" else "wavefront stages",
-                         "kernel_ms_avg": k_ms, "flop_per_test": FLOP_PER_TEST,
+                         "kernel": "trace_kernel" if args.kernel == "mega" else "wavefront stages",
+                         "kernel_ms_avg": k_ms, "render_ms_avg": float(np.mean(launch_ms)),
+                         "flop_per_test": FLOP_PER_TEST,
                          "tests_per_launch": tests_per_launch,
                          "tests_per_path": counters["tests"] / max(1, counters["paths"]),
                          "segments_per_path": counters["segments"] / max(1, counters["paths"]),

@@ -76,8 +76,11 @@ typedef struct {
   float tmin;               /* reference: (float)0.001 (c/main.c:264)           */
   uint32_t seed;            /* seed of the counter generator                    */
   uint32_t kernel;          /* RT_KERNEL_*                                      */
-  uint32_t flags;           /* reserved, 0                                      */
+  uint32_t flags;           /* RT_FLAG_* or 0                                   */
 } rt_job;
+
+/* also fill the cycle and lane-occupancy counters of rt_counters (slower) */
+#define RT_FLAG_PROFILE 1u
 
 /* Device-side event counts accumulated by the kernels since the last reset. */
 typedef struct {
@@ -85,6 +88,11 @@ typedef struct {
   uint64_t segments;        /* closest-hit scans (calls of hit_scene, c/main.c:264) */
   uint64_t tests;           /* ray-sphere filter tests executed in those scans  */
   uint64_t candidates;      /* tests that went on to the exact evaluation       */
+  /* the rest only with RT_FLAG_PROFILE, summed over waves */
+  uint64_t wave_iterations;      /* bounce-loop iterations                      */
+  uint64_t live_lane_iterations; /* lanes with a live path in those iterations  */
+  uint64_t cycles_scan, cycles_drain, cycles_shade, cycles_total; /* shader clocks */
+  uint64_t realtime_total;       /* the waves' lifetimes in 100 MHz ticks: shader clock = cycles_total / realtime_total * 100 MHz */
 } rt_counters;
 
 typedef struct rt_ctx rt_ctx;
@@ -126,9 +134,13 @@ int rt_render_host(rt_ctx *ctx, const rt_camera *cam, const rt_job *job,
                    uint8_t *h_rgb8, float *h_linear, int32_t *h_first_hit,
                    uint32_t *h_hit_sum);
 
-/* Duration of the kernels of the last finished render on this context,
- * measured with HIP events on the stream they ran on (milliseconds). */
+/* Duration of the last render on this context (trace and resolve kernels of
+ * every sample batch), measured with HIP events on the stream they ran on
+ * (milliseconds).  Waits for that render. */
 int rt_ctx_last_kernel_ms(rt_ctx *ctx, float *ms);
+/* Duration of the trace kernel(s) alone of the render `back` renders ago
+ * (0 = the last; the context keeps 32), summed over its sample batches. */
+int rt_ctx_trace_ms(rt_ctx *ctx, int back, float *ms);
 int rt_ctx_counters(rt_ctx *ctx, rt_counters *out, int reset);
 
 /* ---- unit-level entry points (used by the parity tests) ---- */

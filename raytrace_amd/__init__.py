@@ -88,10 +88,10 @@ def device_count():
 
 
 def Job(nx, ny, nsamples, max_depth=50, seed=0, row0=0, tile_rows=None, tile_stride=None, n_tiles=1,
-        kernel=KERNEL_MEGA, tmin=np.float32(0.001)):
+        kernel=KERNEL_MEGA, tmin=np.float32(0.001), flags=0):
     tile_rows = (ny - row0) if tile_rows is None else tile_rows
     tile_stride = tile_rows if tile_stride is None else tile_stride
-    return RtJob(nx, ny, row0, tile_rows, tile_stride, n_tiles, nsamples, max_depth, float(tmin), seed, kernel, 0)
+    return RtJob(nx, ny, row0, tile_rows, tile_stride, n_tiles, nsamples, max_depth, float(tmin), seed, kernel, flags)
 
 
 def job_rows(job):
@@ -169,6 +169,12 @@ class Renderer:
     def last_kernel_ms(self):
         ms = C.c_float()
         N.check(N.device.rt_ctx_last_kernel_ms(self._h, C.byref(ms)), "rt_ctx_last_kernel_ms")
+        return ms.value
+
+    def trace_ms(self, back=0):
+        """Trace-kernel time of the render `back` renders ago (HIP events of the library, on its stream)."""
+        ms = C.c_float()
+        N.check(N.device.rt_ctx_trace_ms(self._h, back, C.byref(ms)), "rt_ctx_trace_ms")
         return ms.value
 
     def counters(self, reset=False):

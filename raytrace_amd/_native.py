@@ -46,7 +46,9 @@ class RtJob(C.Structure):
 
 
 class RtCounters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("paths", "segments", "tests", "candidates")]
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "segments", "tests", "candidates", "wave_iterations",
+                                          "live_lane_iterations", "cycles_scan", "cycles_drain", "cycles_shade",
+                                          "cycles_total", "realtime_total")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -80,6 +82,7 @@ DEVICE_SYMBOLS = {
     "rt_render_host": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtJob), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "rt_ctx_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rt_ctx_trace_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "rt_ctx_counters": (C.c_int, [C.c_void_p, C.POINTER(RtCounters), C.c_int]),
     "rt_debug_closest_hit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p,
                                        C.c_void_p]),

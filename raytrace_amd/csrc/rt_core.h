@@ -188,6 +188,53 @@ RT_HD float filter_discriminant(const FilterRay &f, float cx, float cy, float cz
   return rt_fma(f.na, c0, rt_fma(b, b, f.naaa));
 }
 
+// The same for two spheres at once on packed FP32 (v_pk_fma_f32: two floats
+// per lane per instruction, the form that reaches the chip's FP32 peak).  The
+// arithmetic per half is exactly filter_discriminant's, so the two give the
+// same bits.
+#if defined(__clang__)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#else
+typedef float f32x2 __attribute__((vector_size(8)));
+#endif
+
+RT_HD f32x2 splat2(float v) {
+  f32x2 r;
+  r[0] = v;
+  r[1] = v;
+  return r;
+}
+
+RT_HD f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_elementwise_fma(a, b, c);
+#else
+  f32x2 r;
+  r[0] = __builtin_fmaf(a[0], b[0], c[0]);
+  r[1] = __builtin_fmaf(a[1], b[1], c[1]);
+  return r;
+#endif
+}
+
+struct FilterRay2 {  // FilterRay with every coefficient in both halves
+  f32x2 nbx, nby, nbz, ab, m2ax, m2ay, m2az, na, naaa;
+};
+
+RT_HD FilterRay2 widen(const FilterRay &f) {
+  FilterRay2 w;
+  w.nbx = splat2(f.nbx); w.nby = splat2(f.nby); w.nbz = splat2(f.nbz); w.ab = splat2(f.ab);
+  w.m2ax = splat2(f.m2ax); w.m2ay = splat2(f.m2ay); w.m2az = splat2(f.m2az);
+  w.na = splat2(f.na); w.naaa = splat2(f.naaa);
+  return w;
+}
+
+// cx = {cx of sphere 2p, cx of sphere 2p+1}, ...
+RT_HD f32x2 filter_discriminant2(const FilterRay2 &f, f32x2 cx, f32x2 cy, f32x2 cz, f32x2 kprime) {
+  f32x2 b = pk_fma(f.nbx, cx, pk_fma(f.nby, cy, pk_fma(f.nbz, cz, f.ab)));
+  f32x2 c0 = pk_fma(f.m2ax, cx, pk_fma(f.m2ay, cy, pk_fma(f.m2az, cz, kprime)));
+  return pk_fma(f.na, c0, pk_fma(b, b, f.naaa));
+}
+
 // ------------------------------------------------------------ exact hit test
 
 // c/main.c:214-236 for one sphere.  r2 = radius*radius (a float product, as

@@ -25,6 +25,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -36,31 +37,19 @@ namespace {
 
 // ----------------------------------------------------------------- limits
 constexpr int kBlockThreads = 256;
-constexpr int kWave = 64;
 constexpr int kListCap = 32;          // pending candidates per lane
 constexpr int kChunk = 8;             // spheres per unrolled filter group
 constexpr int kDrainEvery = 16;       // spheres between overflow checks (<= kListCap/2)
 constexpr uint32_t kMaxLdsSpheres = 2048;  // 32 KiB of filter entries per staged batch
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
+constexpr int kNumCounters = 11;
 
 struct DeviceScene {
-  const float4 *filter;   // n_pad entries {cx, cy, cz, K'}; pads never pass
+  const float4 *filter;   // n_pad entries, sphere pairs {cx0,cx1,cy0,cy1},{cz0,cz1,K'0,K'1}; pads never pass
   const float4 *exact;    // n entries {cx, cy, cz, r*r}
   const float4 *mat;      // n entries {albedo rgb, param}
   const float2 *rad_type; // n entries {radius, type as float bits}
   uint32_t n, n_pad;
-};
-
-struct KernelArgs {
-  Camera cam;
-  rt_job job;
-  uint32_t rows;          // rt_job_rows(job)
-  DeviceScene sc;
-  uint8_t *rgb8;
-  float *linear;
-  int32_t *first_hit;
-  uint32_t *hit_sum;
-  unsigned long long *counters;  // paths, segments, tests, candidates
 };
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
@@ -107,27 +96,69 @@ __device__ __forceinline__ void drain_list(const DeviceScene &sc, const uint16_t
   cnt = 0;
 }
 
-// scan LDS entries [0,count): count is a multiple of kDrainEvery
-__device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_filter, uint32_t base,
-                                           uint32_t count, const FilterRay &fr, uint16_t *list, int &cnt, V3 A, V3 B,
-                                           float a, float tmin, HitState &h) {
-  for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
+// One group of kChunk spheres = kChunk float4 of the pair image (see scan_batch).
+struct ChunkRegs {
+  float4 q[kChunk];
+};
+
+__device__ __forceinline__ void load_chunk(ChunkRegs &r, const float4 *lds_pairs, uint32_t first) {
 #pragma unroll
-    for (int g = 0; g < kDrainEvery; g += kChunk) {
-      float d[kChunk];
+  for (int u = 0; u < kChunk; ++u) r.q[u] = lds_pairs[first + u];
+}
+
+// filter the kChunk spheres held in r (global indices first_index..+kChunk-1)
+// and append the ones that pass to this lane's list
+__device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_index, const FilterRay2 &fr,
+                                             uint16_t *list, int &cnt) {
+  f32x2 d[kChunk / 2];
 #pragma unroll
-      for (int u = 0; u < kChunk; ++u) {
-        float4 s = lds_filter[i0 + g + u];
-        d[u] = filter_discriminant(fr, s.x, s.y, s.z, s.w);
-      }
+  for (int u = 0; u < kChunk / 2; ++u) {
+    const float4 q0 = r.q[2 * u], q1 = r.q[2 * u + 1];
+    f32x2 cx = {q0.x, q0.y}, cy = {q0.z, q0.w}, cz = {q1.x, q1.y}, kp = {q1.z, q1.w};
+    d[u] = filter_discriminant2(fr, cx, cy, cz, kp);
+  }
+  // keep the four FMA chains together (interleaved, no dependent back-to-back
+  // issue) instead of letting each sink next to its compare
+  asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+  // Eight compares into eight scalar masks, OR-ed on the scalar unit, one branch
+  // for the whole chunk: no branch waits on a vector compare of its own.
+  unsigned long long m[kChunk];
 #pragma unroll
-      for (int u = 0; u < kChunk; ++u) {
-        if (d[u] > 0.0f) {
-          list[cnt * kBlockThreads] = (uint16_t)(base + i0 + g + u);
+  for (int u = 0; u < kChunk; ++u) m[u] = __ballot(d[u >> 1][u & 1] > 0.0f);
+  const unsigned long long any = ((m[0] | m[1]) | (m[2] | m[3])) | ((m[4] | m[5]) | (m[6] | m[7]));
+  if (any != 0ull) {
+    asm volatile("");  // (keeps the block a branch target; without it the nested ifs are merged)
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      if (m[u] != 0ull) {
+        asm volatile("");
+        if (d[u >> 1][u & 1] > 0.0f) {
+          list[cnt * kBlockThreads] = (uint16_t)(first_index + u);
           ++cnt;
         }
       }
     }
+  }
+}
+
+// Scan LDS entries for `count` spheres (a multiple of kDrainEvery = 2 chunks).
+// The LDS image holds sphere PAIRS: 32 bytes {cx0,cx1, cy0,cy1, cz0,cz1,
+// K'0,K'1}, read as wave-wide broadcast ds_read_b128; one packed FMA then
+// works on both spheres of a pair.  The reads run one chunk ahead of the
+// arithmetic in a second register set, so their latency is covered by the
+// 32 packed FMAs of the chunk in hand rather than waited for.
+__device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, uint32_t base,
+                                           uint32_t count, const FilterRay2 &fr, uint16_t *list, int &cnt, V3 A, V3 B,
+                                           float a, float tmin, HitState &h) {
+  static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
+  ChunkRegs ra, rb;
+  load_chunk(ra, lds_pairs, 0);
+  for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
+    load_chunk(rb, lds_pairs, i0 + kChunk);
+    filter_chunk(ra, base + i0, fr, list, cnt);
+    // the read past the end of the last round stays inside the image and is never used
+    load_chunk(ra, lds_pairs, i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u);
+    filter_chunk(rb, base + i0 + kChunk, fr, list, cnt);
     if (wave_any(cnt > kListCap - kDrainEvery)) drain_list(sc, list, cnt, A, B, a, tmin, h);
   }
 }
@@ -138,8 +169,38 @@ __device__ __forceinline__ uint32_t global_row(const rt_job &job, uint32_t lr) {
   return job.row0 + t * job.tile_stride + (lr - t * job.tile_rows);
 }
 
-template <bool kBatched>
-__global__ __launch_bounds__(kBlockThreads) void mega_kernel(const KernelArgs args) {
+// ---- work decomposition of the trace kernel
+//
+// A work item is one camera path.  The job's compact pixel rows are cut into
+// 8x8 pixel tiles; item id = ((tile * SB) + s) * 64 + l is sample s (of this
+// launch's batch of SB samples) of pixel l of the tile (l & 7 across, l >> 3
+// down).  Waves draw chunks of kChunkItems consecutive ids from one global
+// counter and hand the ids of a chunk to whichever lanes are idle, so a wave
+// starts on 64 neighbouring pixels and stays full until the queue is empty.
+// Every path's radiance goes to rad[s][pixel] (with its first-hit index in
+// the fourth word); resolve_kernel then adds each pixel's samples in sample
+// order, which is the reference's summation order (c/main.c:462-469).
+constexpr uint32_t kChunkItems = 512;
+
+struct TraceArgs {
+  Camera cam;
+  rt_job job;
+  uint32_t rows;          // compact rows of the job
+  uint32_t tiles_x;       // ceil(nx / 8)
+  uint32_t sample0;       // first sample of this batch
+  uint32_t batch;         // SB: samples in this batch
+  uint32_t total_items;   // tiles * SB * 64
+  DeviceScene sc;
+  float4 *rad;            // [SB][rows*nx] {r, g, b, first-hit index bits}
+  unsigned int *queue;    // next unclaimed item id
+  unsigned long long *counters;
+};
+
+// kProfile: also accumulate, per wave, the shader cycles spent in the scan, the
+// drain and the shading, and the number of live lanes per bounce iteration
+// (counters 4..9); selected by RT_FLAG_PROFILE, for diagnosis only.
+template <bool kBatched, bool kProfile>
+__global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DeviceScene &sc = args.sc;
   const rt_job &job = args.job;
@@ -148,48 +209,86 @@ __global__ __launch_bounds__(kBlockThreads) void mega_kernel(const KernelArgs ar
   uint16_t *lds_list = reinterpret_cast<uint16_t *>(smem + (size_t)lds_entries * sizeof(float4));
 
   const uint32_t tid = threadIdx.x;
-  const uint32_t lane = tid & 63u, wave = tid >> 6;
-  // 8x8 pixels per wave, waves 2x2 in the workgroup
-  const uint32_t col = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-  const uint32_t lrow = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-  const bool valid = col < job.nx && lrow < args.rows;
-  const uint32_t grow = valid ? global_row(job, lrow) : 0u;
-  const uint32_t pixel = grow * job.nx + col;      // key of the counter streams
-  const uint32_t up = job.ny - 1u - grow;          // rows below: j-1 of c/main.c:466
+  const uint32_t lane = tid & 63u;
   uint16_t *my_list = lds_list + tid;
+  const uint32_t npix = args.rows * job.nx;
 
   if (!kBatched) {
     for (uint32_t i = tid; i < sc.n_pad; i += kBlockThreads) lds_filter[i] = sc.filter[i];
     __syncthreads();
   }
 
-  bool alive = valid;
-  uint32_t sample = 0, depth = 0;
-  V3 A = v3(0, 0, 0), B = v3(0, 0, 1), color = v3(1, 1, 1), sum = v3(0, 0, 0);
-  Rng g{0u, 0u};
-  int32_t fh0 = -1;
-  uint32_t hsum = 0;
-  unsigned long long n_seg = 0, n_cand = 0, n_paths = 0;
+  // wave-uniform queue state
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
 
-  auto start_sample = [&]() {
-    g.key = path_key(job.seed, pixel, sample);
-    g.k = 0;
-    float x, y;
-    pixel_xy(col, up, job.nx, job.ny, g, x, y);
-    camera_ray(args.cam, x, y, g, A, B);
-    color = v3(1.0f, 1.0f, 1.0f);
-    depth = 0;
-  };
-  if (alive) start_sample();
+  bool alive = false;
+  uint32_t depth = 0, out_index = 0;
+  int32_t first_hit = -1;
+  V3 A = v3(0, 0, 0), B = v3(0, 0, 1), color = v3(1, 1, 1);
+  Rng g{0u, 0u};
+  uint32_t n_seg = 0, n_cand = 0, n_paths = 0;   // per lane; far below 2^32
+  unsigned long long c_scan = 0, c_drain = 0, c_shade = 0, n_iter = 0, n_live = 0;
+  const unsigned long long c_begin = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long r_begin = kProfile ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   for (;;) {
+    // ---- (0): hand new paths to idle lanes
+    const unsigned long long idle_mask = __ballot(!alive);
+    if (idle_mask != 0ull && !exhausted) {
+      if (pool_next == pool_end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(args.queue, kChunkItems);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= args.total_items) {
+          exhausted = true;
+        } else {
+          pool_next = base;
+          pool_end = min(base + kChunkItems, args.total_items);
+        }
+      }
+      const uint32_t avail = pool_end - pool_next;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+      if (!alive && rank < avail) {
+        const uint32_t id = pool_next + rank;
+        const uint32_t l = id & 63u, ts = id >> 6;
+        const uint32_t tile = ts / args.batch, s_local = ts - tile * args.batch;
+        const uint32_t ty = tile / args.tiles_x, tx = tile - ty * args.tiles_x;
+        const uint32_t col = tx * 8u + (l & 7u), lrow = ty * 8u + (l >> 3);
+        if (col < job.nx && lrow < args.rows) {
+          const uint32_t grow = global_row(job, lrow);
+          const uint32_t sample = args.sample0 + s_local;
+          g.key = path_key(job.seed, grow * job.nx + col, sample);   // keyed by the global pixel
+          g.k = 0;
+          float x, y;
+          pixel_xy(col, job.ny - 1u - grow, job.nx, job.ny, g, x, y);  // rows below = j-1 of c/main.c:466
+          camera_ray(args.cam, x, y, g, A, B);
+          color = v3(1.0f, 1.0f, 1.0f);
+          depth = 0;
+          first_hit = -1;
+          out_index = s_local * npix + lrow * job.nx + col;
+          alive = true;
+        }
+      }
+      pool_next += min((uint32_t)__popcll(idle_mask), avail);
+    }
     if (kBatched) {
-      if (!__syncthreads_or(alive ? 1 : 0)) break;
+      if (!__syncthreads_or((alive || !exhausted) ? 1 : 0)) break;
     } else {
-      if (!wave_any(alive)) break;
+      if (!wave_any(alive)) {
+        if (exhausted) break;
+        continue;   // a chunk of off-image ids: draw again
+      }
     }
     // ---- (1)+(2): closest hit
-    FilterRay fr = alive ? make_filter_ray(A, B) : dead_ray();
+    unsigned long long c0 = 0, c1 = 0, c2 = 0;
+    if (kProfile) {
+      n_iter++;
+      n_live += (unsigned long long)__popcll(__ballot(alive));
+      c0 = __builtin_amdgcn_s_memtime();
+    }
+    FilterRay2 fr = widen(alive ? make_filter_ray(A, B) : dead_ray());
     const float a = dot(B, B);
     HitState h{kFltMax, -1, 0u};
     int cnt = 0;
@@ -204,17 +303,16 @@ __global__ __launch_bounds__(kBlockThreads) void mega_kernel(const KernelArgs ar
     } else {
       scan_batch(sc, lds_filter, 0u, sc.n_pad, fr, my_list, cnt, A, B, a, job.tmin, h);
     }
+    if (kProfile) c1 = __builtin_amdgcn_s_memtime();
     drain_list(sc, my_list, cnt, A, B, a, job.tmin, h);
+    if (kProfile) c2 = __builtin_amdgcn_s_memtime();
 
     // ---- (3): shade
     if (alive) {
       n_seg++;
       n_cand += h.cand;
       bool done = false;
-      if (depth == 0) {
-        hsum += (uint32_t)(h.index + 1);
-        if (sample == 0) fh0 = h.index;
-      }
+      if (depth == 0) first_hit = h.index;
       if (h.index >= 0) {
         float4 e = sc.exact[h.index];
         float4 m4 = sc.mat[h.index];
@@ -241,40 +339,92 @@ __global__ __launch_bounds__(kBlockThreads) void mega_kernel(const KernelArgs ar
         done = true;
       }
       if (done) {
-        sum = sum + color;                     // c/main.c:468
+        args.rad[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
         n_paths++;
-        sample++;
-        if (sample < job.nsamples) {
-          start_sample();
-        } else {
-          alive = false;
-          V3 mean;
-          uint8_t rgb[3];
-          finish_pixel(sum, job.nsamples, mean, rgb);
-          size_t o = (size_t)lrow * job.nx + col;
-          args.rgb8[3 * o + 0] = rgb[0];
-          args.rgb8[3 * o + 1] = rgb[1];
-          args.rgb8[3 * o + 2] = rgb[2];
-          if (args.linear) {
-            args.linear[3 * o + 0] = mean.x;
-            args.linear[3 * o + 1] = mean.y;
-            args.linear[3 * o + 2] = mean.z;
-          }
-          if (args.first_hit) args.first_hit[o] = fh0;
-          if (args.hit_sum) args.hit_sum[o] = hsum;
-        }
+        alive = false;
       }
+    }
+    if (kProfile) {
+      unsigned long long c3 = __builtin_amdgcn_s_memtime();
+      c_scan += c1 - c0;
+      c_drain += c2 - c1;
+      c_shade += c3 - c2;
     }
   }
 
+  if (kProfile && lane == 0 && args.counters) {
+    atomicAdd(&args.counters[4], n_iter);
+    atomicAdd(&args.counters[5], n_live);
+    atomicAdd(&args.counters[6], c_scan);
+    atomicAdd(&args.counters[7], c_drain);
+    atomicAdd(&args.counters[8], c_shade);
+    atomicAdd(&args.counters[9], __builtin_amdgcn_s_memtime() - c_begin);
+    atomicAdd(&args.counters[10], __builtin_amdgcn_s_memrealtime() - r_begin);
+  }
   // event counts: one atomic per wave and counter
-  unsigned long long w_paths = wave_sum(n_paths), w_seg = wave_sum(n_seg), w_cand = wave_sum(n_cand);
+  unsigned long long w_paths = wave_sum((unsigned long long)n_paths), w_seg = wave_sum((unsigned long long)n_seg),
+                     w_cand = wave_sum((unsigned long long)n_cand);
   if (lane == 0 && args.counters) {
     atomicAdd(&args.counters[0], w_paths);
     atomicAdd(&args.counters[1], w_seg);
     atomicAdd(&args.counters[2], w_seg * (unsigned long long)sc.n);
     atomicAdd(&args.counters[3], w_cand);
   }
+}
+
+// Sample accumulation and gamma (c/main.c:462-477): one lane per pixel adds
+// this batch's samples in sample order to the running sum carried in `acc`
+// ({r, g, b sum, hit_sum bits} per pixel) and, on the last batch, divides,
+// takes the square root, scrubs NaN and quantises.
+struct ResolveArgs {
+  const float4 *rad;
+  float4 *acc;
+  int32_t *fh_acc;        // first-hit index of sample 0, carried across batches
+  uint32_t npix, batch, nsamples;
+  int first_batch, last_batch;
+  uint8_t *rgb8;
+  float *linear;
+  int32_t *first_hit;
+  uint32_t *hit_sum;
+};
+
+__global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs args) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= args.npix) return;
+  V3 sum = v3(0.0f, 0.0f, 0.0f);
+  uint32_t hsum = 0;
+  int32_t fh0 = -1;
+  if (!args.first_batch) {
+    float4 a = args.acc[p];
+    sum = v3(a.x, a.y, a.z);
+    hsum = (uint32_t)__float_as_int(a.w);
+    fh0 = args.fh_acc[p];
+  }
+  for (uint32_t s = 0; s < args.batch; ++s) {
+    float4 v = args.rad[(size_t)s * args.npix + p];
+    sum = sum + v3(v.x, v.y, v.z);               // c/main.c:468, in sample order
+    int32_t fh = __float_as_int(v.w);
+    hsum += (uint32_t)(fh + 1);
+    if (args.first_batch && s == 0) fh0 = fh;
+  }
+  if (!args.last_batch) {
+    args.acc[p] = make_float4(sum.x, sum.y, sum.z, __int_as_float((int)hsum));
+    args.fh_acc[p] = fh0;
+    return;
+  }
+  V3 mean;
+  uint8_t rgb[3];
+  finish_pixel(sum, args.nsamples, mean, rgb);
+  args.rgb8[3 * (size_t)p + 0] = rgb[0];
+  args.rgb8[3 * (size_t)p + 1] = rgb[1];
+  args.rgb8[3 * (size_t)p + 2] = rgb[2];
+  if (args.linear) {
+    args.linear[3 * (size_t)p + 0] = mean.x;
+    args.linear[3 * (size_t)p + 1] = mean.y;
+    args.linear[3 * (size_t)p + 2] = mean.z;
+  }
+  if (args.first_hit) args.first_hit[p] = fh0;
+  if (args.hit_sum) args.hit_sum[p] = hsum;
 }
 
 // ---- unit-level kernels
@@ -292,7 +442,7 @@ __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene 
     A = v3(rays[6 * r + 0], rays[6 * r + 1], rays[6 * r + 2]);
     B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
   }
-  FilterRay fr = alive ? make_filter_ray(A, B) : dead_ray();
+  FilterRay2 fr = widen(alive ? make_filter_ray(A, B) : dead_ray());
   const float a = dot(B, B);
   HitState h{tmax, -1, 0u};
   int cnt = 0;
@@ -361,12 +511,22 @@ struct rt_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the whole of the last render
   bool timed = false;
+  // trace-kernel event pairs of the last kHistory renders (a render has one pair per sample batch)
+  static constexpr int kHistory = 32;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events[kHistory];
+  int trace_used[kHistory] = {};
+  long renders = 0;
   DevBuf<float4> filter, exact, mat;
   DevBuf<float2> rad_type;
   uint32_t n = 0, n_pad = 0;
   DevBuf<unsigned long long> counters;
+  DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
+  DevBuf<float4> rad;                // per-path radiance of one sample batch
+  DevBuf<float4> acc;                // running per-pixel sums between batches
+  DevBuf<int32_t> fh_acc;
+  int num_cus = 256;
   DevBuf<uint8_t> out_rgb8;
   DevBuf<float> out_linear;
   DevBuf<int32_t> out_first_hit;
@@ -393,34 +553,94 @@ DeviceScene scene_view(const rt_ctx *c) {
   return DeviceScene{c->filter.p, c->exact.p, c->mat.p, c->rad_type.p, c->n, c->n_pad};
 }
 
-size_t mega_lds_bytes(uint32_t n_pad) {
+size_t trace_lds_bytes(uint32_t n_pad) {
   uint32_t entries = n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres;
   return (size_t)entries * sizeof(float4) + (size_t)kListCap * kBlockThreads * sizeof(uint16_t);
 }
 
-int launch_mega(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *rgb8, float *linear, int32_t *first_hit,
-                uint32_t *hit_sum) {
-  KernelArgs a;
+// samples per launch: the radiance buffer holds batch * pixels float4 and is
+// kept under kRadBudgetBytes
+constexpr size_t kRadBudgetBytes = (size_t)3 << 30;
+
+uint32_t batch_size(uint32_t npix, uint32_t nsamples) {
+  size_t per_sample = (size_t)npix * sizeof(float4);
+  size_t fit = kRadBudgetBytes / per_sample;
+  if (fit < 1) fit = 1;
+  return (uint32_t)(fit < nsamples ? fit : nsamples);
+}
+
+int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *rgb8, float *linear, int32_t *first_hit,
+                  uint32_t *hit_sum) {
   static_assert(sizeof(Camera) == sizeof(rt_camera), "camera layouts differ");
-  std::memcpy(&a.cam, cam, sizeof a.cam);
-  a.job = *job;
-  a.rows = rt_job_rows(job);
-  a.sc = scene_view(c);
-  a.rgb8 = rgb8;
-  a.linear = linear;
-  a.first_hit = first_hit;
-  a.hit_sum = hit_sum;
-  a.counters = c->counters.p;
-  dim3 grid((job->nx + 15u) / 16u, (a.rows + 15u) / 16u);
-  size_t lds = mega_lds_bytes(c->n_pad);
+  const uint32_t rows = rt_job_rows(job);
+  const uint32_t npix = rows * job->nx;
+  const uint32_t tiles_x = (job->nx + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
+  const uint32_t batch = batch_size(npix, job->nsamples);
+  if ((uint64_t)tiles_x * tiles_y * batch * 64u > 0xfffffff0ull - kChunkItems * 4096ull)
+    return fail(RT_ERR_LIMIT, "too many paths in one launch");
+  int rc;
+  if ((rc = c->rad.reserve((size_t)batch * npix))) return rc;
+  const bool multi = batch < job->nsamples;
+  if (multi && ((rc = c->acc.reserve(npix)) || (rc = c->fh_acc.reserve(npix)))) return rc;
+
+  TraceArgs t;
+  std::memcpy(&t.cam, cam, sizeof t.cam);
+  t.job = *job;
+  t.rows = rows;
+  t.tiles_x = tiles_x;
+  t.sc = scene_view(c);
+  t.rad = c->rad.p;
+  t.queue = c->queue.p;
+  t.counters = c->counters.p;
+  const size_t lds = trace_lds_bytes(c->n_pad);
+  const bool batched = c->n_pad > kMaxLdsSpheres, profile = (job->flags & RT_FLAG_PROFILE) != 0;
+  // persistent workgroups: enough to fill every CU at the kernel's occupancy;
+  // surplus ones find the queue empty and leave
+  const dim3 grid((unsigned)(c->num_cus * 4)), block(kBlockThreads);
+
+  const int slot = (int)(c->renders % rt_ctx::kHistory);
+  auto &pairs = c->trace_events[slot];
+  int used = 0;
   RT_HIP(hipEventRecord(c->ev_begin, c->stream));
-  if (c->n_pad <= kMaxLdsSpheres) {
-    hipLaunchKernelGGL(mega_kernel<false>, grid, dim3(kBlockThreads), lds, c->stream, a);
-  } else {
-    hipLaunchKernelGGL(mega_kernel<true>, grid, dim3(kBlockThreads), lds, c->stream, a);
+  for (uint32_t s0 = 0; s0 < job->nsamples; s0 += batch) {
+    if ((int)pairs.size() <= used) {
+      hipEvent_t e0, e1;
+      RT_HIP(hipEventCreate(&e0));
+      RT_HIP(hipEventCreate(&e1));
+      pairs.emplace_back(e0, e1);
+    }
+    const uint32_t sb = job->nsamples - s0 < batch ? job->nsamples - s0 : batch;
+    t.sample0 = s0;
+    t.batch = sb;
+    t.total_items = tiles_x * tiles_y * sb * 64u;
+    RT_HIP(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), c->stream));
+    RT_HIP(hipEventRecord(pairs[used].first, c->stream));
+    if (!batched && !profile) hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, c->stream, t);
+    if (!batched && profile) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, c->stream, t);
+    if (batched && !profile) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, c->stream, t);
+    if (batched && profile) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, c->stream, t);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(pairs[used].second, c->stream));
+    ++used;
+    ResolveArgs r;
+    r.rad = c->rad.p;
+    r.acc = c->acc.p;
+    r.fh_acc = c->fh_acc.p;
+    r.npix = npix;
+    r.batch = sb;
+    r.nsamples = job->nsamples;
+    r.first_batch = s0 == 0;
+    r.last_batch = s0 + sb >= job->nsamples;
+    r.rgb8 = rgb8;
+    r.linear = linear;
+    r.first_hit = first_hit;
+    r.hit_sum = hit_sum;
+    hipLaunchKernelGGL(resolve_kernel, dim3((npix + 255u) / 256u), dim3(256), 0, c->stream, r);
+    RT_HIP(hipGetLastError());
   }
-  RT_HIP(hipGetLastError());
   RT_HIP(hipEventRecord(c->ev_end, c->stream));
+  c->trace_used[slot] = used;
+  c->renders++;
   c->timed = true;
   return RT_OK;
 }
@@ -469,12 +689,16 @@ int rt_ctx_create(int device, rt_ctx **out) {
     return fail(RT_ERR_HIP, std::string("context set-up: ") + hipGetErrorString(e));
   }
   c->stream = c->own_stream;
-  int rc = c->counters.reserve(4);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    c->num_cus = prop.multiProcessorCount;
+  int rc = c->counters.reserve(kNumCounters);
+  if (rc == RT_OK) rc = c->queue.reserve(1);
   if (rc != RT_OK) {
     rt_ctx_destroy(c);
     return rc;
   }
-  e = hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream);
+  e = hipMemsetAsync(c->counters.p, 0, kNumCounters * sizeof(unsigned long long), c->stream);
   if (e != hipSuccess) {
     rt_ctx_destroy(c);
     return fail(RT_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
@@ -492,10 +716,19 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->mat.release();
   c->rad_type.release();
   c->counters.release();
+  c->queue.release();
+  c->rad.release();
+  c->acc.release();
+  c->fh_acc.release();
   c->out_rgb8.release();
   c->out_linear.release();
   c->out_first_hit.release();
   c->out_hit_sum.release();
+  for (auto &slot : c->trace_events)
+    for (auto &pr : slot) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -531,10 +764,10 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   const uint32_t n_pad = (uint32_t)((n + kDrainEvery - 1) / kDrainEvery * kDrainEvery);
   std::vector<float4> filter(n_pad), exact(n), mat(n);
   std::vector<float2> rad_type(n);
+  std::vector<FilterSphere> fs(n_pad);
   for (size_t i = 0; i < n; ++i) {
     const rt_sphere &s = spheres[i];
-    FilterSphere f = make_filter_sphere(s.center[0], s.center[1], s.center[2], s.radius);
-    filter[i] = make_float4(f.cx, f.cy, f.cz, f.kprime);
+    fs[i] = make_filter_sphere(s.center[0], s.center[1], s.center[2], s.radius);
     exact[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);  // c/main.c:219
     mat[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
     float type_bits;
@@ -543,7 +776,12 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     rad_type[i] = make_float2(s.radius, type_bits);
   }
   // pads: K' so large that b*b - a*K' is negative for any ray
-  for (size_t i = n; i < n_pad; ++i) filter[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0e30f);
+  for (size_t i = n; i < n_pad; ++i) fs[i] = FilterSphere{0.0f, 0.0f, 0.0f, 1.0e30f};
+  // pair image: entries 2p, 2p+1 = {cx0,cx1,cy0,cy1}, {cz0,cz1,K'0,K'1} of spheres 2p, 2p+1
+  for (size_t p2 = 0; p2 < n_pad; p2 += 2) {
+    filter[p2] = make_float4(fs[p2].cx, fs[p2 + 1].cx, fs[p2].cy, fs[p2 + 1].cy);
+    filter[p2 + 1] = make_float4(fs[p2].cz, fs[p2 + 1].cz, fs[p2].kprime, fs[p2 + 1].kprime);
+  }
   int rc;
   if ((rc = c->filter.reserve(n_pad)) || (rc = c->exact.reserve(n)) || (rc = c->mat.reserve(n)) ||
       (rc = c->rad_type.reserve(n)))
@@ -567,7 +805,7 @@ int rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t
   if (rt_job_rows(job) == 0) return fail(RT_ERR_ARG, "job covers no rows");
   RT_HIP(hipSetDevice(c->device));
   if (job->kernel == RT_KERNEL_WAVEFRONT) return fail(RT_ERR_ARG, "wavefront variant not built");
-  return launch_mega(c, cam, job, d_rgb8, d_linear, d_first_hit, d_hit_sum);
+  return launch_render(c, cam, job, d_rgb8, d_linear, d_first_hit, d_hit_sum);
 }
 
 int rt_render_host(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *h_rgb8, float *h_linear,
@@ -605,19 +843,43 @@ int rt_ctx_last_kernel_ms(rt_ctx *c, float *ms) {
   return RT_OK;
 }
 
+int rt_ctx_trace_ms(rt_ctx *c, int back, float *ms) {
+  if (!c || !ms) return fail(RT_ERR_ARG, "null argument");
+  if (back < 0 || back >= rt_ctx::kHistory || (long)back >= c->renders)
+    return fail(RT_ERR_ARG, "no such render in the history");
+  RT_HIP(hipSetDevice(c->device));
+  const int slot = (int)((c->renders - 1 - back) % rt_ctx::kHistory);
+  float total = 0.0f;
+  for (int i = 0; i < c->trace_used[slot]; ++i) {
+    float t = 0.0f;
+    RT_HIP(hipEventSynchronize(c->trace_events[slot][i].second));
+    RT_HIP(hipEventElapsedTime(&t, c->trace_events[slot][i].first, c->trace_events[slot][i].second));
+    total += t;
+  }
+  *ms = total;
+  return RT_OK;
+}
+
 int rt_ctx_counters(rt_ctx *c, rt_counters *out, int reset) {
   if (!c) return fail(RT_ERR_ARG, "ctx is null");
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));
   if (out) {
-    unsigned long long v[4];
+    unsigned long long v[kNumCounters];
     RT_HIP(hipMemcpy(v, c->counters.p, sizeof v, hipMemcpyDeviceToHost));
     out->paths = v[0];
     out->segments = v[1];
     out->tests = v[2];
     out->candidates = v[3];
+    out->wave_iterations = v[4];
+    out->live_lane_iterations = v[5];
+    out->cycles_scan = v[6];
+    out->cycles_drain = v[7];
+    out->cycles_shade = v[8];
+    out->cycles_total = v[9];
+    out->realtime_total = v[10];
   }
-  if (reset) RT_HIP(hipMemset(c->counters.p, 0, 4 * sizeof(unsigned long long)));
+  if (reset) RT_HIP(hipMemset(c->counters.p, 0, kNumCounters * sizeof(unsigned long long)));
   return RT_OK;
 }
 

@@ -191,6 +191,6 @@ int rth_write_ppm(FILE *fp, const uint8_t *rgb8, size_t w, size_t h) {
   if (!fp || !rgb8) return RT_ERR_ARG;
   if (fprintf(fp, "P6\n%zu %zu 255\n", w, h) < 0) return RT_ERR_ARG;          /* c/main.c:412 */
   fflush(fp);
-  if (w * h && fwrite(rgb8, 3 * w * h, 1, fp) != 1) return RT_ERR_ARG;
+  if (w != 0 && h != 0 && fwrite(rgb8, 3 * w * h, 1, fp) != 1) return RT_ERR_ARG;
   return RT_OK;
 }

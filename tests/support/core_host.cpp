@@ -52,6 +52,31 @@ uint64_t core_filter_check(const rt_sphere *s, size_t n, const float *rays, size
   return bad;
 }
 
+// packed two-sphere filter against the one-sphere form: number of halves whose bits differ (must be 0)
+uint64_t core_filter_pair_mismatches(const rt_sphere *s, size_t n, const float *rays, size_t n_rays) {
+  std::vector<FilterSphere> fs(n + 1);
+  for (size_t i = 0; i < n; i++) fs[i] = make_filter_sphere(s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius);
+  fs[n] = FilterSphere{0.0f, 0.0f, 0.0f, 1.0e30f};
+  uint64_t bad = 0;
+  for (size_t r = 0; r < n_rays; r++) {
+    V3 A = v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]);
+    V3 B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
+    FilterRay fr = make_filter_ray(A, B);
+    FilterRay2 fw = widen(fr);
+    for (size_t i = 0; i + 1 <= n; i += 2) {
+      f32x2 cx = {fs[i].cx, fs[i + 1].cx}, cy = {fs[i].cy, fs[i + 1].cy}, cz = {fs[i].cz, fs[i + 1].cz};
+      f32x2 kp = {fs[i].kprime, fs[i + 1].kprime};
+      f32x2 d = filter_discriminant2(fw, cx, cy, cz, kp);
+      for (int h = 0; h < 2; h++) {
+        float one = filter_discriminant(fr, fs[i + h].cx, fs[i + h].cy, fs[i + h].cz, fs[i + h].kprime);
+        float two = d[h];
+        if (std::memcmp(&one, &two, 4) != 0) bad++;
+      }
+    }
+  }
+  return bad;
+}
+
 static int closest(const rt_sphere *s, const FilterSphere *fs, size_t n, V3 A, V3 B, float tmin, float tmax,
                    float &t_out, uint64_t *cand) {
   FilterRay fr = make_filter_ray(A, B);

@@ -55,6 +55,13 @@ def test_filter_has_no_false_negatives(core, rt, builder):
     assert passed.value < 1.35 * pos.value + 3 * len(rays)   # ... and the filter is not much looser
 
 
+def test_packed_filter_equals_scalar_filter(core, rt):
+    sc = rt.random_scene()
+    rays = random_rays(np.random.default_rng(5), 2000, sc)
+    core.core_filter_pair_mismatches.restype = C.c_uint64
+    assert core.core_filter_pair_mismatches(vp(sc), C.c_size_t(len(sc)), vp(rays), C.c_size_t(len(rays))) == 0
+
+
 def test_filtered_scan_equals_reference_scan(core, rt, oracle):
     rng = np.random.default_rng(4)
     for sc in (rt.small_scene(), rt.random_scene(), rt.glass_scene()):
