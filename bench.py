@@ -110,15 +110,15 @@ def main():
     torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
     r.upload(sc)
+    from raytrace_amd.sharding import FrameShards, gather_frame
     tile_rows = 8
-    job = rt.interleaved_job(nx, ny, spp_total, rank, world, tile_rows, max_depth=max_depth, seed=0, kernel=kernel)
+    shards = FrameShards(nx, ny, spp_total, world, tile_rows, max_depth=max_depth, seed=0, kernel=kernel)
+    shards.check()
+    job = shards.job(rank)
     my_rows = rt.job_rows(job)
-    max_rows = max(rt.job_rows(rt.interleaved_job(nx, ny, spp_total, q, world, tile_rows)) for q in range(world))
-    tiles = torch.zeros((max_rows, nx, 3), dtype=torch.uint8, device=dev)       # this rank's tiles, padded
+    tiles = torch.zeros((shards.max_rows, nx, 3), dtype=torch.uint8, device=dev)       # this rank's tiles, padded
     gathered = [torch.zeros_like(tiles) for _ in range(world)] if (world > 1 and rank == 0) else None
     frame = torch.zeros((ny, nx, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
-    row_index = [torch.as_tensor(rt.job_row_indices(rt.interleaved_job(nx, ny, spp_total, q, world, tile_rows)), device=dev)
-                 for q in range(world)] if rank == 0 else None
 
     def step(ev=None):
         if ev:
@@ -126,13 +126,7 @@ def main():
         r.render_device(cam, job, tiles.data_ptr())
         if ev:
             ev[1].record(stream)
-        if world > 1:
-            dist.gather(tiles, gathered, dst=0)
-            if rank == 0:
-                for q in range(world):
-                    frame[row_index[q]] = gathered[q][: len(row_index[q])]
-        else:
-            frame[row_index[0]] = tiles[:my_rows]
+        gather_frame(shards, tiles, rank, frame, gathered)     # the only communication: tiles -> rank 0
 
     def fence():
         if world > 1:

@@ -1,0 +1,46 @@
+"""The command-line renderer (raytrace_amd/host/main.c): option handling mirrors
+the reference's CLI (c/main.c:53-138); the GPU test checks the PPM it writes."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAY = os.path.join(ROOT, "raytrace_amd", "lib", "ray")
+
+
+def run(*args):
+    return subprocess.run([RAY, *args], capture_output=True, timeout=120)
+
+
+def test_no_output_file_prints_usage_and_exits_1():
+    p = run()
+    assert p.returncode == 1 and b"Usage:" in p.stderr                    # c/main.c:126-128
+
+
+@pytest.mark.parametrize("flag", ["-n", "-t", "-x", "-y", "-d"])
+def test_non_positive_numbers_are_rejected(flag):
+    for bad in ("0", "-3", "12abc"):
+        p = run(flag, bad, "-o", "-")
+        assert p.returncode == 1 and b"must be a positive integer" in p.stderr   # c/main.c:100-106
+
+
+def test_extension_handling(tmp_path):
+    assert b"missing file name extension" in run("-o", str(tmp_path / "noext")).stderr     # c/main.c:73-77
+    assert b"unsupported file extension" in run("-o", str(tmp_path / "a.gif")).stderr     # c/main.c:84-89
+
+
+@pytest.mark.gpu
+def test_cli_renders_the_same_bytes_as_the_library(tmp_path, renderer, rt):
+    out = tmp_path / "o.ppm"
+    p = run("-s", "final", "-x", "200", "-y", "100", "-n", "4", "-t", "2", "-o", str(out))
+    assert p.returncode == 0, p.stderr
+    blob = out.read_bytes()
+    assert blob.startswith(b"P6\n200 100 255\n")                          # c/main.c:412
+    renderer.upload(rt.random_scene())
+    want = renderer.render_host(rt.camera_default(200, 100), rt.Job(200, 100, 4, seed=0), debug=False)["rgb8"]
+    assert blob[len(b"P6\n200 100 255\n"):] == want.tobytes()
+    p2 = run("-s", "final", "-x", "200", "-y", "100", "-n", "4", "-o", "-")           # '-' = stdout, c/main.c:68-70
+    assert p2.returncode == 0 and hashlib.sha256(p2.stdout).digest() == hashlib.sha256(blob).digest()

@@ -164,3 +164,41 @@ def test_full_size_properties(renderer, rt):
     top = out["linear"][:50]
     assert np.all(top[..., 2] >= top[..., 0]) and top.min() > 0.5      # blue-white gradient
     assert np.isfinite(out["linear"]).all()
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+def test_psnr_against_high_spp_reference(renderer, rt, oracle):
+    """North-star quality gate: >= 40 dB against a high-spp reference render.
+    The reference is the CPU oracle at 4096 spp on a reduced frame (its own
+    seed); the GPU frame is 1024 spp, the sample count of BASELINE config 2."""
+    sc = rt.random_scene()
+    renderer.upload(sc)
+    nx, ny = 160, 90
+    cam = rt.camera_default(nx, ny)
+    ref = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, 4096, seed=12345, host_threads=16,
+                            want_debug=False)["rgb8"]
+    got = renderer.render_host(cam, rt.Job(nx, ny, 1024, seed=1), debug=False)["rgb8"]
+    low = renderer.render_host(cam, rt.Job(nx, ny, 16, seed=1), debug=False)["rgb8"]
+    p_hi, p_lo = psnr(got, ref), psnr(low, ref)
+    print(f"PSNR vs 4096-spp oracle: 1024 spp {p_hi:.2f} dB, 16 spp {p_lo:.2f} dB")
+    assert p_hi >= 40.0
+    assert p_hi > p_lo + 10.0      # and it converges: 64x the samples, ~18 dB more
+
+
+def test_sample_batches_do_not_change_the_sum(renderer, rt):
+    """A render whose radiance buffer needs several sample batches adds the
+    samples in the same order as one that fits a single batch."""
+    sc = rt.small_scene()
+    renderer.upload(sc)
+    nx, ny, spp = 2048, 1200, 100           # 2.46 Mpixel * 100 spp * 16 B > the 3 GiB radiance budget
+    cam = rt.camera_default(nx, ny)
+    big = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=6))
+    rows = slice(600, 616)
+    part = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=6, row0=600, tile_rows=16))   # single batch
+    assert np.array_equal(big["rgb8"][rows], part["rgb8"])
+    assert np.array_equal(big["linear"][rows].view(np.uint32), part["linear"].view(np.uint32))
+    assert np.array_equal(big["hit_sum"][rows], part["hit_sum"]) and np.array_equal(big["first_hit"][rows], part["first_hit"])
