@@ -427,6 +427,224 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs args) {
   if (args.hit_sum) args.hit_sum[p] = hsum;
 }
 
+// ---------------------------------------------------------------------------
+// Material-sorted wavefront variant (RT_KERNEL_WAVEFRONT).  Same arithmetic,
+// same work items and the same radiance buffer as trace_kernel, but the bounce
+// loop is cut into stages that hand paths over through global memory:
+//   wf_generate   dead slots of a fixed pool take the next unclaimed paths
+//   wf_intersect  closest hit for every live slot, then the slot id is pushed
+//                 on the queue of what it hit: sky, matte, metal or dielectric
+//   wf_shade<Q>   one launch per queue: every lane runs the same material
+// It exists to measure what sorting by material buys against the megakernel's
+// divergent shading, and what the state traffic and the launches cost.
+
+struct WfPool {
+  float4 *org;     // {A.xyz, t of the hit}
+  float4 *dir;     // {B.xyz, hit index bits}
+  float4 *col;     // {colour rgb, first-hit index bits}
+  uint4 *misc;     // {rng key, rng k, depth, out_index};  out_index == kWfDead: free slot
+  uint32_t *qlist; // 4 queues of up to `slots` slot ids
+  uint32_t *ctrl;  // [0] next item, [1..4] queue counts, [5] paths finished
+  uint32_t slots;
+};
+constexpr uint32_t kWfDead = 0xffffffffu;
+constexpr int kWfNext = 0, kWfQueue = 1, kWfFinished = 5, kWfCtrlWords = 8;
+
+// Every workgroup of the wavefront stages handles kWfPerBlock slots in
+// kWfSub passes of 256 and talks to the global counters once per counter:
+// a single word takes only ~90 atomics per microsecond, which per-wave
+// reservations (65,536 per stage and round) would make the bottleneck.
+constexpr int kWfSub = 4;
+constexpr uint32_t kWfPerBlock = kWfSub * kBlockThreads;
+
+__global__ __launch_bounds__(kBlockThreads) void wf_generate(const TraceArgs args, const WfPool pool) {
+  __shared__ uint32_t n_dead, base_id;
+  const rt_job &job = args.job;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) n_dead = 0;
+  __syncthreads();
+  uint32_t rank[kWfSub];
+  bool dead[kWfSub];
+#pragma unroll
+  for (int sub = 0; sub < kWfSub; ++sub) {
+    const uint32_t slot = blockIdx.x * kWfPerBlock + sub * kBlockThreads + tid;
+    dead[sub] = slot < pool.slots && pool.misc[slot].w == kWfDead;
+    rank[sub] = dead[sub] ? atomicAdd(&n_dead, 1u) : 0u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t b = args.total_items;
+    if (n_dead != 0 && pool.ctrl[kWfNext] < args.total_items) b = atomicAdd(&pool.ctrl[kWfNext], n_dead);
+    base_id = b;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int sub = 0; sub < kWfSub; ++sub) {
+    if (!dead[sub]) continue;
+    const uint32_t slot = blockIdx.x * kWfPerBlock + sub * kBlockThreads + tid;
+    const uint32_t id = base_id + rank[sub];
+    if (id >= args.total_items) continue;
+    const uint32_t l = id & 63u, ts = id >> 6;
+    const uint32_t tile = ts / args.batch, s_local = ts - tile * args.batch;
+    const uint32_t ty = tile / args.tiles_x, tx = tile - ty * args.tiles_x;
+    const uint32_t col = tx * 8u + (l & 7u), lrow = ty * 8u + (l >> 3);
+    if (col >= job.nx || lrow >= args.rows) continue;   // off-image id: the slot stays free
+    const uint32_t grow = global_row(job, lrow);
+    Rng g{path_key(job.seed, grow * job.nx + col, args.sample0 + s_local), 0u};
+    float x, y;
+    pixel_xy(col, job.ny - 1u - grow, job.nx, job.ny, g, x, y);
+    V3 A, B;
+    camera_ray(args.cam, x, y, g, A, B);
+    pool.org[slot] = make_float4(A.x, A.y, A.z, 0.0f);
+    pool.dir[slot] = make_float4(B.x, B.y, B.z, __int_as_float(-1));
+    pool.col[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(-1));
+    pool.misc[slot] = make_uint4(g.key, g.k, 0u, s_local * (args.rows * job.nx) + lrow * job.nx + col);
+  }
+}
+
+template <bool kBatched>
+__global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs args, const WfPool pool) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ uint32_t qcnt[4], qbase[4];
+  const DeviceScene &sc = args.sc;
+  const uint32_t lds_entries = kBatched ? kMaxLdsSpheres : sc.n_pad;
+  float4 *lds_filter = reinterpret_cast<float4 *>(smem);
+  uint16_t *lds_list = reinterpret_cast<uint16_t *>(smem + (size_t)lds_entries * sizeof(float4));
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  uint16_t *my_list = lds_list + tid;
+  if (tid < 4) qcnt[tid] = 0;
+  if (!kBatched) {
+    for (uint32_t i = tid; i < sc.n_pad; i += kBlockThreads) lds_filter[i] = sc.filter[i];
+  }
+  __syncthreads();
+  int q[kWfSub];
+  uint32_t pos[kWfSub];
+  uint32_t n_seg = 0, n_cand = 0;
+#pragma unroll 1
+  for (int sub = 0; sub < kWfSub; ++sub) {
+    const uint32_t slot = blockIdx.x * kWfPerBlock + sub * kBlockThreads + tid;
+    const bool alive = slot < pool.slots && pool.misc[slot].w != kWfDead;
+    q[sub] = -1;
+    pos[sub] = 0;
+    if (kBatched) {
+      if (!__syncthreads_or(alive ? 1 : 0)) continue;
+    } else {
+      if (!wave_any(alive)) continue;
+    }
+    V3 A = v3(0, 0, 0), B = v3(0, 0, 1);
+    if (alive) {
+      float4 o = pool.org[slot], d = pool.dir[slot];
+      A = v3(o.x, o.y, o.z);
+      B = v3(d.x, d.y, d.z);
+    }
+    FilterRay2 fr = widen(alive ? make_filter_ray(A, B) : dead_ray());
+    const float a = dot(B, B);
+    HitState h{kFltMax, -1, 0u};
+    int cnt = 0;
+    if (kBatched) {
+      for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
+        uint32_t count = min(kMaxLdsSpheres, sc.n_pad - base);
+        __syncthreads();
+        for (uint32_t i = tid; i < count; i += kBlockThreads) lds_filter[i] = sc.filter[base + i];
+        __syncthreads();
+        scan_batch(sc, lds_filter, base, count, fr, my_list, cnt, A, B, a, args.job.tmin, h);
+      }
+    } else {
+      scan_batch(sc, lds_filter, 0u, sc.n_pad, fr, my_list, cnt, A, B, a, args.job.tmin, h);
+    }
+    drain_list(sc, my_list, cnt, A, B, a, args.job.tmin, h);
+    if (alive) {
+      // queue 0 = sky, 1 + material type otherwise
+      q[sub] = h.index < 0 ? 0 : 1 + __float_as_int(sc.rad_type[h.index].y);
+      pos[sub] = atomicAdd(&qcnt[q[sub]], 1u);
+      pool.org[slot].w = h.closest;
+      pool.dir[slot].w = __int_as_float(h.index);
+      n_seg++;
+      n_cand += h.cand;
+    }
+  }
+  __syncthreads();
+  if (tid < 4 && qcnt[tid] != 0) qbase[tid] = atomicAdd(&pool.ctrl[kWfQueue + tid], qcnt[tid]);
+  __syncthreads();
+#pragma unroll
+  for (int sub = 0; sub < kWfSub; ++sub) {
+    if (q[sub] >= 0) {
+      const uint32_t slot = blockIdx.x * kWfPerBlock + sub * kBlockThreads + tid;
+      pool.qlist[(size_t)q[sub] * pool.slots + qbase[q[sub]] + pos[sub]] = slot;
+    }
+  }
+  unsigned long long w_seg = wave_sum((unsigned long long)n_seg), w_cand = wave_sum((unsigned long long)n_cand);
+  if (lane == 0 && args.counters && w_seg) {
+    atomicAdd(&args.counters[1], w_seg);
+    atomicAdd(&args.counters[2], w_seg * (unsigned long long)sc.n);
+    atomicAdd(&args.counters[3], w_cand);
+  }
+}
+
+// Q: 0 sky, 1 matte, 2 metal, 3 dielectric
+template <int Q>
+__global__ __launch_bounds__(kBlockThreads) void wf_shade(const TraceArgs args, const WfPool pool) {
+  const uint32_t count = pool.ctrl[kWfQueue + Q];
+  if (blockIdx.x * kWfPerBlock >= count) return;
+  uint32_t n_finished = 0;
+#pragma unroll 1
+  for (int sub = 0; sub < kWfSub; ++sub) {
+    const uint32_t i = blockIdx.x * kWfPerBlock + sub * kBlockThreads + threadIdx.x;
+    if (i >= count) continue;
+    bool finished = false;
+    const uint32_t slot = pool.qlist[(size_t)Q * pool.slots + i];
+    const float4 o = pool.org[slot], d = pool.dir[slot], c4 = pool.col[slot];
+    uint4 mi = pool.misc[slot];
+    V3 A = v3(o.x, o.y, o.z), B = v3(d.x, d.y, d.z), color = v3(c4.x, c4.y, c4.z);
+    const int index = __float_as_int(d.w);
+    int first_hit = __float_as_int(c4.w);
+    if (mi.z == 0u) first_hit = index;
+    if (Q == 0) {
+      color = color * sky(B);                    // c/main.c:274-279
+      finished = true;
+    } else {
+      const float4 e = args.sc.exact[index];
+      const float4 m4 = args.sc.mat[index];
+      const float radius = args.sc.rad_type[index].x;
+      V3 p = A + o.w * B;
+      V3 n = (p - v3(e.x, e.y, e.z)) / radius;
+      Material m{Q - 1, v3(m4.x, m4.y, m4.z), m4.w};
+      Rng g{mi.x, mi.y};
+      V3 atten, nA, nB;
+      if (scatter(m, A, B, p, n, g, atten, nA, nB)) {
+        color = atten * color;
+        mi.y = g.k;
+        mi.z += 1u;
+        finished = mi.z >= args.job.max_depth;
+        if (!finished) {
+          pool.org[slot] = make_float4(nA.x, nA.y, nA.z, 0.0f);
+          pool.dir[slot] = make_float4(nB.x, nB.y, nB.z, __int_as_float(-1));
+          pool.col[slot] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
+          pool.misc[slot] = mi;
+        }
+      } else {
+        color = v3(0.0f, 0.0f, 0.0f);            // c/main.c:270-272
+        finished = true;
+      }
+    }
+    if (finished) {
+      args.rad[mi.w] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
+      pool.misc[slot].w = kWfDead;
+      n_finished++;
+    }
+  }
+  __shared__ uint32_t block_finished;
+  if (threadIdx.x == 0) block_finished = 0;
+  __syncthreads();
+  const unsigned long long w = wave_sum((unsigned long long)n_finished);
+  if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&block_finished, (uint32_t)w);
+  __syncthreads();
+  if (threadIdx.x == 0 && block_finished) {
+    atomicAdd(&pool.ctrl[kWfFinished], block_finished);
+    if (args.counters) atomicAdd(&args.counters[0], (unsigned long long)block_finished);
+  }
+}
+
 // ---- unit-level kernels
 
 __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene sc, const float *rays, uint32_t n_rays,
@@ -527,6 +745,10 @@ struct rt_ctx {
   DevBuf<float4> acc;                // running per-pixel sums between batches
   DevBuf<int32_t> fh_acc;
   int num_cus = 256;
+  // slot pool of the wavefront variant
+  DevBuf<float4> wf_org, wf_dir, wf_col;
+  DevBuf<uint4> wf_misc;
+  DevBuf<uint32_t> wf_qlist, wf_ctrl;
   DevBuf<uint8_t> out_rgb8;
   DevBuf<float> out_linear;
   DevBuf<int32_t> out_first_hit;
@@ -569,6 +791,43 @@ uint32_t batch_size(uint32_t npix, uint32_t nsamples) {
   return (uint32_t)(fit < nsamples ? fit : nsamples);
 }
 
+// One sample batch through the wavefront stages.  The host loop needs the
+// finished-path count to know when to stop; it reads it back every few rounds.
+constexpr uint32_t kWfSlots = 1u << 22;
+
+int run_wavefront_batch(rt_ctx *c, const TraceArgs &t, uint32_t valid_paths, bool batched, size_t lds) {
+  int rc;
+  const uint32_t slots = kWfSlots;
+  if ((rc = c->wf_org.reserve(slots)) || (rc = c->wf_dir.reserve(slots)) || (rc = c->wf_col.reserve(slots)) ||
+      (rc = c->wf_misc.reserve(slots)) || (rc = c->wf_qlist.reserve((size_t)4 * slots)) ||
+      (rc = c->wf_ctrl.reserve(kWfCtrlWords)))
+    return rc;
+  WfPool pool{c->wf_org.p, c->wf_dir.p, c->wf_col.p, c->wf_misc.p, c->wf_qlist.p, c->wf_ctrl.p, slots};
+  RT_HIP(hipMemsetAsync(pool.misc, 0xff, (size_t)slots * sizeof(uint4), c->stream));
+  RT_HIP(hipMemsetAsync(pool.ctrl, 0, kWfCtrlWords * sizeof(uint32_t), c->stream));
+  const dim3 grid((slots + kWfPerBlock - 1) / kWfPerBlock), block(kBlockThreads);
+  const uint32_t min_rounds = (t.total_items + slots - 1) / slots;
+  for (uint32_t round = 0;; ++round) {
+    RT_HIP(hipMemsetAsync(pool.ctrl + kWfQueue, 0, 4 * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(wf_generate, grid, block, 0, c->stream, t, pool);
+    if (batched) hipLaunchKernelGGL(wf_intersect<true>, grid, block, lds, c->stream, t, pool);
+    else hipLaunchKernelGGL(wf_intersect<false>, grid, block, lds, c->stream, t, pool);
+    hipLaunchKernelGGL(wf_shade<0>, grid, block, 0, c->stream, t, pool);
+    hipLaunchKernelGGL(wf_shade<1>, grid, block, 0, c->stream, t, pool);
+    hipLaunchKernelGGL(wf_shade<2>, grid, block, 0, c->stream, t, pool);
+    hipLaunchKernelGGL(wf_shade<3>, grid, block, 0, c->stream, t, pool);
+    RT_HIP(hipGetLastError());
+    if (round + 1 >= min_rounds && (round & 3u) == 3u) {
+      uint32_t finished = 0;
+      RT_HIP(hipMemcpyAsync(&finished, pool.ctrl + kWfFinished, sizeof finished, hipMemcpyDeviceToHost, c->stream));
+      RT_HIP(hipStreamSynchronize(c->stream));
+      if (finished >= valid_paths) break;
+      if (round > min_rounds + 4u * t.job.max_depth + 64u) return fail(RT_ERR_HIP, "wavefront variant did not drain");
+    }
+  }
+  return RT_OK;
+}
+
 int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *rgb8, float *linear, int32_t *first_hit,
                   uint32_t *hit_sum) {
   static_assert(sizeof(Camera) == sizeof(rt_camera), "camera layouts differ");
@@ -576,7 +835,7 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
   const uint32_t npix = rows * job->nx;
   const uint32_t tiles_x = (job->nx + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
   const uint32_t batch = batch_size(npix, job->nsamples);
-  if ((uint64_t)tiles_x * tiles_y * batch * 64u > 0xfffffff0ull - kChunkItems * 4096ull)
+  if ((uint64_t)tiles_x * tiles_y * batch * 64u > 0xfffffff0ull - 4ull * kWfSlots)
     return fail(RT_ERR_LIMIT, "too many paths in one launch");
   int rc;
   if ((rc = c->rad.reserve((size_t)batch * npix))) return rc;
@@ -615,11 +874,15 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
     t.total_items = tiles_x * tiles_y * sb * 64u;
     RT_HIP(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), c->stream));
     RT_HIP(hipEventRecord(pairs[used].first, c->stream));
-    if (!batched && !profile) hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, c->stream, t);
-    if (!batched && profile) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, c->stream, t);
-    if (batched && !profile) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, c->stream, t);
-    if (batched && profile) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, c->stream, t);
-    RT_HIP(hipGetLastError());
+    if (job->kernel == RT_KERNEL_WAVEFRONT) {
+      if ((rc = run_wavefront_batch(c, t, npix * sb, batched, lds))) return rc;
+    } else {
+      if (!batched && !profile) hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, c->stream, t);
+      if (!batched && profile) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, c->stream, t);
+      if (batched && !profile) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, c->stream, t);
+      if (batched && profile) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, c->stream, t);
+      RT_HIP(hipGetLastError());
+    }
     RT_HIP(hipEventRecord(pairs[used].second, c->stream));
     ++used;
     ResolveArgs r;
@@ -720,6 +983,12 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->rad.release();
   c->acc.release();
   c->fh_acc.release();
+  c->wf_org.release();
+  c->wf_dir.release();
+  c->wf_col.release();
+  c->wf_misc.release();
+  c->wf_qlist.release();
+  c->wf_ctrl.release();
   c->out_rgb8.release();
   c->out_linear.release();
   c->out_first_hit.release();
@@ -804,7 +1073,6 @@ int rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t
   if (c->n == 0) return fail(RT_ERR_NO_SCENE, "no scene uploaded");
   if (rt_job_rows(job) == 0) return fail(RT_ERR_ARG, "job covers no rows");
   RT_HIP(hipSetDevice(c->device));
-  if (job->kernel == RT_KERNEL_WAVEFRONT) return fail(RT_ERR_ARG, "wavefront variant not built");
   return launch_render(c, cam, job, d_rgb8, d_linear, d_first_hit, d_hit_sum);
 }
 

@@ -166,6 +166,21 @@ def test_full_size_properties(renderer, rt):
     assert np.isfinite(out["linear"]).all()
 
 
+@pytest.mark.parametrize("scene,nx,ny,spp", [("small_scene", 200, 100, 8), ("random_scene", 320, 180, 8), ("glass_scene", 160, 90, 16)])
+def test_wavefront_variant_is_bit_identical_to_the_megakernel(renderer, rt, scene, nx, ny, spp):
+    """The material-sorted wavefront stages share the arithmetic, so every output must match exactly."""
+    renderer.upload(getattr(rt, scene)())
+    cam = rt.camera_default(nx, ny)
+    mega = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=3, kernel=rt.KERNEL_MEGA))
+    renderer.counters(reset=True)
+    wave = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=3, kernel=rt.KERNEL_WAVEFRONT))
+    c = renderer.counters(reset=True)
+    assert c["paths"] == nx * ny * spp
+    for k in ("rgb8", "first_hit", "hit_sum"):
+        assert np.array_equal(mega[k], wave[k]), k
+    assert np.array_equal(mega["linear"].view(np.uint32), wave["linear"].view(np.uint32))
+
+
 def psnr(a, b):
     mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
     return 10.0 * np.log10(255.0 ** 2 / mse)
