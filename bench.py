@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
     ap.add_argument("--kernel", default="mega", choices=["mega", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-scan", action="store_true", help="RT_FLAG_FULL_SCAN: filter every sphere for every ray (no group culling)")
     args = ap.parse_args()
 
     import numpy as np
@@ -112,7 +113,8 @@ def main():
     r.upload(sc)
     from raytrace_amd.sharding import FrameShards, gather_frame
     tile_rows = 8
-    shards = FrameShards(nx, ny, spp_total, world, tile_rows, max_depth=max_depth, seed=0, kernel=kernel)
+    shards = FrameShards(nx, ny, spp_total, world, tile_rows, max_depth=max_depth, seed=0, kernel=kernel,
+                         flags=2 if args.full_scan else 0)
     shards.check()
     job = shards.job(rank)
     my_rows = rt.job_rows(job)
@@ -175,7 +177,7 @@ def main():
             "config": {"workload": f"{args.workload}: {scene_name} {len(sc)} spheres, {nx}x{ny}, {spp_total} spp "
                                    f"({spp} per GPU), max_depth {max_depth}, deterministic counter-RNG mode, "
                                    f"{tile_rows}-row tiles round-robin over {world} GPU(s), gather to rank 0",
-                       "kernel": args.kernel, "paths_per_step": total_paths_per_step,
+                       "kernel": args.kernel, "scan": "full" if args.full_scan else "group-culled", "paths_per_step": total_paths_per_step,
                        "msamples_per_s": total_paths_per_step * args.steps / dt / 1e6},
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,

@@ -19,18 +19,20 @@ sc = rt.random_scene(args.half_extent) if args.scene == "random_scene" else geta
 r = rt.Renderer(0)
 r.upload(sc)
 cam = rt.camera_default(args.nx, args.ny)
-for flags in (0, 1):
+ap_flags = [(0, "culled"), (1, "culled+profile"), (2, "full"), (3, "full+profile")]
+for flags, label in ap_flags:
     job = rt.Job(args.nx, args.ny, args.spp, seed=0, flags=flags)
     r.render_host(cam, job, debug=False)
     r.counters(reset=True)
     r.render_host(cam, job, debug=False)
     ms = r.last_kernel_ms()
     c = r.counters(reset=True)
-    out = {"flags": flags, "kernel_ms": ms, "paths_per_s": c["paths"] / (ms * 1e-3), **c}
-    if flags:
+    out = {"mode": label, "flags": flags, "kernel_ms": ms, "paths_per_s": c["paths"] / (ms * 1e-3), **c}
+    if flags & 1:
         tot = c["cycles_total"]
         out.update(frac_scan=c["cycles_scan"] / tot, frac_drain=c["cycles_drain"] / tot, frac_shade=c["cycles_shade"] / tot,
                    shader_clock_ghz=c['cycles_total'] / max(1, c['realtime_total']) * 0.1,
+                   own_groups_per_segment=c['own_groups'] / c['segments'], wave_groups_per_segment=c['wave_groups'] / c['segments'],
                    lane_occupancy=c["live_lane_iterations"] / (64.0 * c["wave_iterations"]),
                    scan_cycles_per_wave_iteration=c["cycles_scan"] / c["wave_iterations"],
                    drain_cycles_per_wave_iteration=c["cycles_drain"] / c["wave_iterations"],

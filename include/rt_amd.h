@@ -81,18 +81,22 @@ typedef struct {
 
 /* also fill the cycle and lane-occupancy counters of rt_counters (slower) */
 #define RT_FLAG_PROFILE 1u
+/* filter every sphere for every ray instead of skipping groups of spheres
+ * whose bounding sphere no ray of the wave can touch; same image either way */
+#define RT_FLAG_FULL_SCAN 2u
 
 /* Device-side event counts accumulated by the kernels since the last reset. */
 typedef struct {
   uint64_t paths;           /* camera paths finished                            */
   uint64_t segments;        /* closest-hit scans (calls of hit_scene, c/main.c:264) */
-  uint64_t tests;           /* ray-sphere filter tests executed in those scans  */
+  uint64_t tests;           /* ray-sphere filter tests executed in those scans (group bounds included) */
   uint64_t candidates;      /* tests that went on to the exact evaluation       */
   /* the rest only with RT_FLAG_PROFILE, summed over waves */
   uint64_t wave_iterations;      /* bounce-loop iterations                      */
   uint64_t live_lane_iterations; /* lanes with a live path in those iterations  */
   uint64_t cycles_scan, cycles_drain, cycles_shade, cycles_total; /* shader clocks */
   uint64_t realtime_total;       /* the waves' lifetimes in 100 MHz ticks: shader clock = cycles_total / realtime_total * 100 MHz */
+  uint64_t own_groups, wave_groups; /* summed over live lanes and segments: sphere groups the lane's own ray needed / its wave scanned */
 } rt_counters;
 
 typedef struct rt_ctx rt_ctx;

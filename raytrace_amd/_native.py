@@ -48,7 +48,7 @@ class RtJob(C.Structure):
 class RtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("paths", "segments", "tests", "candidates", "wave_iterations",
                                           "live_lane_iterations", "cycles_scan", "cycles_drain", "cycles_shade",
-                                          "cycles_total", "realtime_total")]
+                                          "cycles_total", "realtime_total", "own_groups", "wave_groups")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

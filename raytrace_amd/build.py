@@ -36,7 +36,8 @@ def _run(cmd):
 
 def build_device(force=False):
     src = os.path.join(PKG, "csrc", "rt_device.hip")
-    deps = [src, os.path.join(PKG, "csrc", "rt_core.h"), os.path.join(ROOT, "include", "rt_amd.h")]
+    deps = [src, os.path.join(PKG, "csrc", "rt_core.h"), os.path.join(PKG, "csrc", "rt_cluster.h"),
+            os.path.join(ROOT, "include", "rt_amd.h")]
     out = os.path.join(LIB, "libraytrace_amd.so")
     if force or _newer(out, deps):
         os.makedirs(LIB, exist_ok=True)

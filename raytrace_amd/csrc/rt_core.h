@@ -95,15 +95,18 @@ RT_HD double next_uniform(Rng &g) {
   return unit_from_bits(r);
 }
 
-// c/vec.c:64-72
+// c/vec.c:64-72.  The reference tests norm = sqrtf(s) against 1 and
+// FLT_EPSILON; for a correctly rounded square root sqrtf(s) < 1 exactly when
+// s < 1 (the float below 1 has a root that rounds below 1) and sqrtf(s) <
+// 2^-23 exactly when s < 2^-46, so the loop tests s itself.
 RT_HD V3 unit_ball(Rng &g) {
   for (;;) {
     float ux = (float)next_uniform(g);
     float uy = (float)next_uniform(g);
     float uz = (float)next_uniform(g);
     V3 u = 2.0f * v3(ux, uy, uz) - v3(1.0f, 1.0f, 1.0f);
-    float len = length(u);
-    if (len < 1.0f && !(__builtin_fabsf(len) < kFltEpsilon)) return u;
+    float s = u.x * u.x + u.y * u.y + u.z * u.z;
+    if (s < 1.0f && !(s < 1.4210854715202004e-14f)) return u;   // 2^-46
   }
 }
 

@@ -30,6 +30,7 @@
 
 #include "../../include/rt_amd.h"
 #include "rt_core.h"
+#include "rt_cluster.h"
 
 using namespace rtcore;
 
@@ -42,14 +43,21 @@ constexpr int kChunk = 8;             // spheres per unrolled filter group
 constexpr int kDrainEvery = 16;       // spheres between overflow checks (<= kListCap/2)
 constexpr uint32_t kMaxLdsSpheres = 2048;  // 32 KiB of filter entries per staged batch
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
-constexpr int kNumCounters = 11;
+constexpr int kNumCounters = 13;
+// squared origin distance up to which the group bounds are valid (rt_cluster.h), with a little room
+__device__ __forceinline__ constexpr float rtcluster_limit2() { return 1023.0f; }
 
+// All arrays are in SCAN order (rt_cluster.h): position -> sphere, pads included.
 struct DeviceScene {
   const float4 *filter;   // n_pad entries, sphere pairs {cx0,cx1,cy0,cy1},{cz0,cz1,K'0,K'1}; pads never pass
-  const float4 *exact;    // n entries {cx, cy, cz, r*r}
-  const float4 *mat;      // n entries {albedo rgb, param}
-  const float2 *rad_type; // n entries {radius, type as float bits}
+  const float4 *bounds;   // n_pad/8 entries, group-bound pairs in the same pair layout
+  const float4 *exact;    // n_pad entries {cx, cy, cz, r*r}
+  const float4 *mat;      // n_pad entries {albedo rgb, param}
+  const float2 *rad_type; // n_pad entries {radius, type as float bits}
+  const uint32_t *orig;   // n_pad entries: index in the caller's list (ties go to the lowest), ~0 for pads
+  const uint16_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (lo byte, hi byte)
   uint32_t n, n_pad;
+  float bscale[3];        // axis factors (powers of two) of the space the group bounds live in
 };
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
@@ -64,9 +72,13 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // entries [0, count) in LDS that stand for global sphere indices base+i.
 // Lanes without a ray pass a FilterRay that can never pass (see dead_ray()).
 struct HitState {
-  float closest;
-  int index;
-  uint32_t cand;
+  float closest;    // smallest t so far
+  int index;        // its scan position, -1 for none
+  uint32_t orig;    // its index in the caller's list (0 while there is no hit, so that t == tmax is refused)
+  uint32_t cand;    // exact evaluations done
+  uint32_t tests;   // filter tests done (bounds and spheres; wave-uniform)
+  uint32_t own_groups;   // groups this lane's own ray needed (diagnostic: what a per-ray cull would scan)
+  uint32_t wave_groups;  // groups the wave scanned
 };
 
 __device__ __forceinline__ FilterRay dead_ray() {
@@ -79,16 +91,24 @@ __device__ __forceinline__ FilterRay dead_ray() {
   return f;
 }
 
+// Exact evaluation (c/main.c:214-236) of the listed spheres.  The reference's
+// shrinking-tmax scan returns the smallest first-root-in-(tmin, FLT_MAX) and,
+// among equal t, the lowest index; taking that minimum explicitly gives the
+// same hit in any evaluation order.
 __device__ __forceinline__ void drain_list(const DeviceScene &sc, const uint16_t *list, int &cnt, V3 A, V3 B, float a,
                                            float tmin, HitState &h) {
   for (int j = 0; wave_any(j < cnt); ++j) {
     if (j < cnt) {
-      uint32_t idx = list[j * kBlockThreads];
-      float4 e = sc.exact[idx];
+      uint32_t pos = list[j * kBlockThreads];
+      float4 e = sc.exact[pos];
       float t;
-      if (exact_hit(A, B, a, e.x, e.y, e.z, e.w, tmin, h.closest, t)) {
-        h.closest = t;
-        h.index = (int)idx;
+      if (exact_hit(A, B, a, e.x, e.y, e.z, e.w, tmin, kFltMax, t)) {
+        uint32_t o = sc.orig[pos];
+        if (t < h.closest || (t == h.closest && o < h.orig)) {
+          h.closest = t;
+          h.index = (int)pos;
+          h.orig = o;
+        }
       }
     }
   }
@@ -141,26 +161,126 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
   }
 }
 
-// Scan LDS entries for `count` spheres (a multiple of kDrainEvery = 2 chunks).
-// The LDS image holds sphere PAIRS: 32 bytes {cx0,cx1, cy0,cy1, cz0,cz1,
-// K'0,K'1}, read as wave-wide broadcast ds_read_b128; one packed FMA then
-// works on both spheres of a pair.  The reads run one chunk ahead of the
-// arithmetic in a second register set, so their latency is covered by the
-// 32 packed FMAs of the chunk in hand rather than waited for.
-__device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, uint32_t base,
-                                           uint32_t count, const FilterRay2 &fr, uint16_t *list, int &cnt, V3 A, V3 B,
-                                           float a, float tmin, HitState &h) {
+// Scan `count` spheres (a multiple of kDrainEvery = two groups) whose pair
+// image is in LDS.  The LDS image holds sphere PAIRS: 32 bytes {cx0,cx1,
+// cy0,cy1, cz0,cz1, K'0,K'1}, read as wave-wide broadcast ds_read_b128; one
+// packed FMA then works on both spheres of a pair.
+//
+// kCull = false: every group is filtered; the reads run one chunk ahead of the
+// arithmetic in a second register set, so their latency is covered by the 32
+// packed FMAs of the chunk in hand rather than waited for.
+//
+// kCull = true: each round first filters the bounding spheres of its two groups
+// (one packed evaluation, read one round ahead) and skips a group no lane's ray
+// can touch.  `far` lanes (origin outside the radius the bounds were built
+// for) take every group.
+template <bool kCull>
+__device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, const float4 *lds_bounds,
+                                           uint32_t base, uint32_t count, const FilterRay2 &fr, const FilterRay2 &frb, bool far,
+                                           uint16_t *list, int &cnt, V3 A, V3 B, float a, float tmin, HitState &h) {
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
-  ChunkRegs ra, rb;
-  load_chunk(ra, lds_pairs, 0);
+  if (!kCull) {
+    ChunkRegs ra, rb;
+    load_chunk(ra, lds_pairs, 0);
+    for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
+      load_chunk(rb, lds_pairs, i0 + kChunk);
+      filter_chunk(ra, base + i0, fr, list, cnt);
+      // the read past the end of the last round stays inside the image and is never used
+      load_chunk(ra, lds_pairs, i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u);
+      filter_chunk(rb, base + i0 + kChunk, fr, list, cnt);
+      if (wave_any(cnt > kListCap - kDrainEvery)) drain_list(sc, list, cnt, A, B, a, tmin, h);
+    }
+    return;
+  }
+  const unsigned long long far_mask = __ballot(far);
+  float4 b0 = lds_bounds[0], b1 = lds_bounds[1];
+  uint32_t tests = 0;
   for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
-    load_chunk(rb, lds_pairs, i0 + kChunk);
-    filter_chunk(ra, base + i0, fr, list, cnt);
-    // the read past the end of the last round stays inside the image and is never used
-    load_chunk(ra, lds_pairs, i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u);
-    filter_chunk(rb, base + i0 + kChunk, fr, list, cnt);
+    const uint32_t nr = (i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u) >> 3;   // next round's bounds
+    const float4 n0 = lds_bounds[nr], n1 = lds_bounds[nr + 1];
+    f32x2 bx = {b0.x, b0.y}, by = {b0.z, b0.w}, bz = {b1.x, b1.y}, bk = {b1.z, b1.w};
+    const f32x2 db = filter_discriminant2(frb, bx, by, bz, bk);
+    const unsigned long long m0 = __ballot(db[0] > 0.0f) | far_mask, m1 = __ballot(db[1] > 0.0f) | far_mask;
+    const uint32_t real = sc.round_real[(base + i0) >> 4];
+    tests += 2u;
+    h.own_groups += (db[0] > 0.0f ? 1u : 0u) + (db[1] > 0.0f ? 1u : 0u);
+    h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
+    if (m0 != 0ull) {
+      asm volatile("");
+      ChunkRegs r;
+      load_chunk(r, lds_pairs, i0);
+      filter_chunk(r, base + i0, fr, list, cnt);
+      tests += real & 0xffu;
+    }
+    if (m1 != 0ull) {
+      asm volatile("");
+      ChunkRegs r;
+      load_chunk(r, lds_pairs, i0 + kChunk);
+      filter_chunk(r, base + i0 + kChunk, fr, list, cnt);
+      tests += real >> 8;
+    }
+    b0 = n0;
+    b1 = n1;
     if (wave_any(cnt > kListCap - kDrainEvery)) drain_list(sc, list, cnt, A, B, a, tmin, h);
   }
+  h.tests += tests;
+}
+
+// LDS carve-up shared by every kernel that scans: the pair image of the
+// resident batch, its group bounds, then the per-lane candidate lists.
+struct ScanLds {
+  float4 *pairs;
+  float4 *bounds;
+  uint16_t *list;
+};
+
+__device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entries) {
+  ScanLds l;
+  l.pairs = reinterpret_cast<float4 *>(smem);
+  l.bounds = l.pairs + entries;
+  l.list = reinterpret_cast<uint16_t *>(l.bounds + entries / 8u);
+  return l;
+}
+
+__device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
+                                            uint32_t tid) {
+  for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[i] = sc.filter[base + i];
+  for (uint32_t i = tid; i < count / 8u; i += kBlockThreads) lds.bounds[i] = sc.bounds[base / 8u + i];
+}
+
+// Closest hit of the ray (A, B) of every lane of the workgroup against the
+// whole scene.  Unbatched: the scene is already resident in LDS.  Batched: it
+// is streamed through LDS in kMaxLdsSpheres pieces, which needs every wave of
+// the workgroup here together.  Lanes without a ray pass dead_ray().
+template <bool kBatched, bool kCull>
+__device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const ScanLds &lds, uint32_t tid, bool alive,
+                                                  V3 A, V3 B, float tmin, HitState &h) {
+  FilterRay fr1 = alive ? make_filter_ray(A, B) : dead_ray();
+  const FilterRay2 fr = widen(fr1);
+  // the same ray in the scaled space of the group bounds (power-of-two factors: exact products)
+  FilterRay2 frb = fr;
+  if (kCull) {
+    const V3 sc3 = v3(sc.bscale[0], sc.bscale[1], sc.bscale[2]);
+    frb = widen(alive ? make_filter_ray(sc3 * A, sc3 * B) : dead_ray());
+  }
+  const float a = dot(B, B);
+  // origins beyond the radius the group bounds were derived for scan every group
+  const bool far = alive && !(dot(A, A) < (float)(rtcluster_limit2()));
+  uint16_t *my_list = lds.list + tid;
+  int cnt = 0;
+  if (kBatched) {
+    for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
+      uint32_t count = min(kMaxLdsSpheres, sc.n_pad - base);
+      __syncthreads();
+      stage_batch(sc, lds, base, count, tid);
+      __syncthreads();
+      scan_batch<kCull>(sc, lds.pairs, lds.bounds, base, count, fr, frb, far, my_list, cnt, A, B, a, tmin, h);
+    }
+  } else {
+    scan_batch<kCull>(sc, lds.pairs, lds.bounds, 0u, sc.n_pad, fr, frb, far, my_list, cnt, A, B, a, tmin, h);
+  }
+  if (!kCull) h.tests += sc.n;
+  drain_list(sc, my_list, cnt, A, B, a, tmin, h);
 }
 
 // global row of compact (tile-major) local row lr
@@ -199,22 +319,20 @@ struct TraceArgs {
 // kProfile: also accumulate, per wave, the shader cycles spent in the scan, the
 // drain and the shading, and the number of live lanes per bounce iteration
 // (counters 4..9); selected by RT_FLAG_PROFILE, for diagnosis only.
-template <bool kBatched, bool kProfile>
-__global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceArgs args) {
+// (second launch-bound argument: four waves per SIMD, i.e. at most 128 VGPRs)
+template <bool kBatched, bool kCull, bool kProfile>
+__global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DeviceScene &sc = args.sc;
   const rt_job &job = args.job;
-  const uint32_t lds_entries = kBatched ? kMaxLdsSpheres : sc.n_pad;
-  float4 *lds_filter = reinterpret_cast<float4 *>(smem);
-  uint16_t *lds_list = reinterpret_cast<uint16_t *>(smem + (size_t)lds_entries * sizeof(float4));
+  const ScanLds lds = carve_lds(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
-  uint16_t *my_list = lds_list + tid;
   const uint32_t npix = args.rows * job.nx;
 
   if (!kBatched) {
-    for (uint32_t i = tid; i < sc.n_pad; i += kBlockThreads) lds_filter[i] = sc.filter[i];
+    stage_batch(sc, lds, 0u, sc.n_pad, tid);
     __syncthreads();
   }
 
@@ -228,6 +346,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceArgs ar
   V3 A = v3(0, 0, 0), B = v3(0, 0, 1), color = v3(1, 1, 1);
   Rng g{0u, 0u};
   uint32_t n_seg = 0, n_cand = 0, n_paths = 0;   // per lane; far below 2^32
+  unsigned long long n_tests = 0, n_own = 0, n_wave = 0;
   unsigned long long c_scan = 0, c_drain = 0, c_shade = 0, n_iter = 0, n_live = 0;
   const unsigned long long c_begin = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long r_begin = kProfile ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -288,31 +407,21 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceArgs ar
       n_live += (unsigned long long)__popcll(__ballot(alive));
       c0 = __builtin_amdgcn_s_memtime();
     }
-    FilterRay2 fr = widen(alive ? make_filter_ray(A, B) : dead_ray());
-    const float a = dot(B, B);
-    HitState h{kFltMax, -1, 0u};
-    int cnt = 0;
-    if (kBatched) {
-      for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
-        uint32_t count = min(kMaxLdsSpheres, sc.n_pad - base);
-        __syncthreads();
-        for (uint32_t i = tid; i < count; i += kBlockThreads) lds_filter[i] = sc.filter[base + i];
-        __syncthreads();
-        scan_batch(sc, lds_filter, base, count, fr, my_list, cnt, A, B, a, job.tmin, h);
-      }
-    } else {
-      scan_batch(sc, lds_filter, 0u, sc.n_pad, fr, my_list, cnt, A, B, a, job.tmin, h);
-    }
-    if (kProfile) c1 = __builtin_amdgcn_s_memtime();
-    drain_list(sc, my_list, cnt, A, B, a, job.tmin, h);
-    if (kProfile) c2 = __builtin_amdgcn_s_memtime();
+    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u};
+    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, job.tmin, h);
+    if (kProfile) c1 = c2 = __builtin_amdgcn_s_memtime();
 
     // ---- (3): shade
     if (alive) {
       n_seg++;
       n_cand += h.cand;
+      n_tests += h.tests;
+      if (kProfile) {
+        n_own += h.own_groups;
+        n_wave += h.wave_groups;
+      }
       bool done = false;
-      if (depth == 0) first_hit = h.index;
+      if (depth == 0) first_hit = h.index >= 0 ? (int32_t)h.orig : -1;
       if (h.index >= 0) {
         float4 e = sc.exact[h.index];
         float4 m4 = sc.mat[h.index];
@@ -361,13 +470,20 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const TraceArgs ar
     atomicAdd(&args.counters[9], __builtin_amdgcn_s_memtime() - c_begin);
     atomicAdd(&args.counters[10], __builtin_amdgcn_s_memrealtime() - r_begin);
   }
+  if (kProfile) {
+    unsigned long long w_own = wave_sum(n_own), w_wave = wave_sum(n_wave);
+    if (lane == 0 && args.counters) {
+      atomicAdd(&args.counters[11], w_own);
+      atomicAdd(&args.counters[12], w_wave);
+    }
+  }
   // event counts: one atomic per wave and counter
   unsigned long long w_paths = wave_sum((unsigned long long)n_paths), w_seg = wave_sum((unsigned long long)n_seg),
-                     w_cand = wave_sum((unsigned long long)n_cand);
+                     w_cand = wave_sum((unsigned long long)n_cand), w_tests = wave_sum(n_tests);
   if (lane == 0 && args.counters) {
     atomicAdd(&args.counters[0], w_paths);
     atomicAdd(&args.counters[1], w_seg);
-    atomicAdd(&args.counters[2], w_seg * (unsigned long long)sc.n);
+    atomicAdd(&args.counters[2], w_tests);
     atomicAdd(&args.counters[3], w_cand);
   }
 }
@@ -502,24 +618,20 @@ __global__ __launch_bounds__(kBlockThreads) void wf_generate(const TraceArgs arg
   }
 }
 
-template <bool kBatched>
+template <bool kBatched, bool kCull>
 __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs args, const WfPool pool) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t qcnt[4], qbase[4];
   const DeviceScene &sc = args.sc;
-  const uint32_t lds_entries = kBatched ? kMaxLdsSpheres : sc.n_pad;
-  float4 *lds_filter = reinterpret_cast<float4 *>(smem);
-  uint16_t *lds_list = reinterpret_cast<uint16_t *>(smem + (size_t)lds_entries * sizeof(float4));
+  const ScanLds lds = carve_lds(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  uint16_t *my_list = lds_list + tid;
   if (tid < 4) qcnt[tid] = 0;
-  if (!kBatched) {
-    for (uint32_t i = tid; i < sc.n_pad; i += kBlockThreads) lds_filter[i] = sc.filter[i];
-  }
+  if (!kBatched) stage_batch(sc, lds, 0u, sc.n_pad, tid);
   __syncthreads();
   int q[kWfSub];
   uint32_t pos[kWfSub];
   uint32_t n_seg = 0, n_cand = 0;
+  unsigned long long n_tests = 0;
 #pragma unroll 1
   for (int sub = 0; sub < kWfSub; ++sub) {
     const uint32_t slot = blockIdx.x * kWfPerBlock + sub * kBlockThreads + tid;
@@ -537,30 +649,17 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
       A = v3(o.x, o.y, o.z);
       B = v3(d.x, d.y, d.z);
     }
-    FilterRay2 fr = widen(alive ? make_filter_ray(A, B) : dead_ray());
-    const float a = dot(B, B);
-    HitState h{kFltMax, -1, 0u};
-    int cnt = 0;
-    if (kBatched) {
-      for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
-        uint32_t count = min(kMaxLdsSpheres, sc.n_pad - base);
-        __syncthreads();
-        for (uint32_t i = tid; i < count; i += kBlockThreads) lds_filter[i] = sc.filter[base + i];
-        __syncthreads();
-        scan_batch(sc, lds_filter, base, count, fr, my_list, cnt, A, B, a, args.job.tmin, h);
-      }
-    } else {
-      scan_batch(sc, lds_filter, 0u, sc.n_pad, fr, my_list, cnt, A, B, a, args.job.tmin, h);
-    }
-    drain_list(sc, my_list, cnt, A, B, a, args.job.tmin, h);
+    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u};
+    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, args.job.tmin, h);
     if (alive) {
       // queue 0 = sky, 1 + material type otherwise
       q[sub] = h.index < 0 ? 0 : 1 + __float_as_int(sc.rad_type[h.index].y);
       pos[sub] = atomicAdd(&qcnt[q[sub]], 1u);
       pool.org[slot].w = h.closest;
-      pool.dir[slot].w = __int_as_float(h.index);
+      pool.dir[slot].w = __int_as_float(h.index);      // scan position
       n_seg++;
       n_cand += h.cand;
+      n_tests += h.tests;
     }
   }
   __syncthreads();
@@ -573,10 +672,11 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
       pool.qlist[(size_t)q[sub] * pool.slots + qbase[q[sub]] + pos[sub]] = slot;
     }
   }
-  unsigned long long w_seg = wave_sum((unsigned long long)n_seg), w_cand = wave_sum((unsigned long long)n_cand);
+  unsigned long long w_seg = wave_sum((unsigned long long)n_seg), w_cand = wave_sum((unsigned long long)n_cand),
+                     w_tests = wave_sum(n_tests);
   if (lane == 0 && args.counters && w_seg) {
     atomicAdd(&args.counters[1], w_seg);
-    atomicAdd(&args.counters[2], w_seg * (unsigned long long)sc.n);
+    atomicAdd(&args.counters[2], w_tests);
     atomicAdd(&args.counters[3], w_cand);
   }
 }
@@ -598,7 +698,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_shade(const TraceArgs args, 
     V3 A = v3(o.x, o.y, o.z), B = v3(d.x, d.y, d.z), color = v3(c4.x, c4.y, c4.z);
     const int index = __float_as_int(d.w);
     int first_hit = __float_as_int(c4.w);
-    if (mi.z == 0u) first_hit = index;
+    if (mi.z == 0u) first_hit = index >= 0 ? (int)args.sc.orig[index] : -1;
     if (Q == 0) {
       color = color * sky(B);                    // c/main.c:274-279
       finished = true;
@@ -647,11 +747,11 @@ __global__ __launch_bounds__(kBlockThreads) void wf_shade(const TraceArgs args, 
 
 // ---- unit-level kernels
 
+template <bool kCull>
 __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene sc, const float *rays, uint32_t n_rays,
                                                                      float tmin, float tmax, int32_t *index, float *t) {
   extern __shared__ __align__(16) unsigned char smem[];
-  float4 *lds_filter = reinterpret_cast<float4 *>(smem);
-  uint16_t *lds_list = reinterpret_cast<uint16_t *>(smem + (size_t)kMaxLdsSpheres * sizeof(float4));
+  const ScanLds lds = carve_lds(smem, kMaxLdsSpheres);
   const uint32_t tid = threadIdx.x;
   const uint32_t r = blockIdx.x * kBlockThreads + tid;
   const bool alive = r < n_rays;
@@ -660,21 +760,10 @@ __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene 
     A = v3(rays[6 * r + 0], rays[6 * r + 1], rays[6 * r + 2]);
     B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
   }
-  FilterRay2 fr = widen(alive ? make_filter_ray(A, B) : dead_ray());
-  const float a = dot(B, B);
-  HitState h{tmax, -1, 0u};
-  int cnt = 0;
-  uint16_t *my_list = lds_list + tid;
-  for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
-    uint32_t count = min(kMaxLdsSpheres, sc.n_pad - base);
-    __syncthreads();
-    for (uint32_t i = tid; i < count; i += kBlockThreads) lds_filter[i] = sc.filter[base + i];
-    __syncthreads();
-    scan_batch(sc, lds_filter, base, count, fr, my_list, cnt, A, B, a, tmin, h);
-  }
-  drain_list(sc, my_list, cnt, A, B, a, tmin, h);
+  HitState h{tmax, -1, 0u, 0u, 0u, 0u, 0u};
+  closest_hit_scene<true, kCull>(sc, lds, tid, alive, A, B, tmin, h);
   if (alive) {
-    index[r] = h.index;
+    index[r] = h.index >= 0 ? (int32_t)sc.orig[h.index] : -1;
     t[r] = h.index >= 0 ? h.closest : 0.0f;
   }
 }
@@ -736,9 +825,12 @@ struct rt_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events[kHistory];
   int trace_used[kHistory] = {};
   long renders = 0;
-  DevBuf<float4> filter, exact, mat;
+  DevBuf<float4> filter, bounds, exact, mat;
   DevBuf<float2> rad_type;
+  DevBuf<uint32_t> orig;
+  DevBuf<uint16_t> round_real;
   uint32_t n = 0, n_pad = 0;
+  float bscale[3] = {1.0f, 1.0f, 1.0f};
   DevBuf<unsigned long long> counters;
   DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
   DevBuf<float4> rad;                // per-path radiance of one sample batch
@@ -772,13 +864,15 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->exact.p, c->mat.p, c->rad_type.p, c->n, c->n_pad};
+  return DeviceScene{c->filter.p, c->bounds.p, c->exact.p, c->mat.p, c->rad_type.p, c->orig.p, c->round_real.p, c->n, c->n_pad,
+                     {c->bscale[0], c->bscale[1], c->bscale[2]}};
 }
 
-size_t trace_lds_bytes(uint32_t n_pad) {
-  uint32_t entries = n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres;
-  return (size_t)entries * sizeof(float4) + (size_t)kListCap * kBlockThreads * sizeof(uint16_t);
+size_t scan_lds_bytes(uint32_t entries) {
+  return (size_t)entries * sizeof(float4) + (size_t)(entries / 8u) * sizeof(float4) +
+         (size_t)kListCap * kBlockThreads * sizeof(uint16_t);
 }
+size_t trace_lds_bytes(uint32_t n_pad) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres); }
 
 // samples per launch: the radiance buffer holds batch * pixels float4 and is
 // kept under kRadBudgetBytes
@@ -810,8 +904,11 @@ int run_wavefront_batch(rt_ctx *c, const TraceArgs &t, uint32_t valid_paths, boo
   for (uint32_t round = 0;; ++round) {
     RT_HIP(hipMemsetAsync(pool.ctrl + kWfQueue, 0, 4 * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(wf_generate, grid, block, 0, c->stream, t, pool);
-    if (batched) hipLaunchKernelGGL(wf_intersect<true>, grid, block, lds, c->stream, t, pool);
-    else hipLaunchKernelGGL(wf_intersect<false>, grid, block, lds, c->stream, t, pool);
+    const bool cull = (t.job.flags & RT_FLAG_FULL_SCAN) == 0;
+    if (batched && cull) hipLaunchKernelGGL((wf_intersect<true, true>), grid, block, lds, c->stream, t, pool);
+    if (batched && !cull) hipLaunchKernelGGL((wf_intersect<true, false>), grid, block, lds, c->stream, t, pool);
+    if (!batched && cull) hipLaunchKernelGGL((wf_intersect<false, true>), grid, block, lds, c->stream, t, pool);
+    if (!batched && !cull) hipLaunchKernelGGL((wf_intersect<false, false>), grid, block, lds, c->stream, t, pool);
     hipLaunchKernelGGL(wf_shade<0>, grid, block, 0, c->stream, t, pool);
     hipLaunchKernelGGL(wf_shade<1>, grid, block, 0, c->stream, t, pool);
     hipLaunchKernelGGL(wf_shade<2>, grid, block, 0, c->stream, t, pool);
@@ -877,10 +974,17 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
     if (job->kernel == RT_KERNEL_WAVEFRONT) {
       if ((rc = run_wavefront_batch(c, t, npix * sb, batched, lds))) return rc;
     } else {
-      if (!batched && !profile) hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, c->stream, t);
-      if (!batched && profile) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, c->stream, t);
-      if (batched && !profile) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, c->stream, t);
-      if (batched && profile) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, c->stream, t);
+      const bool cull = (job->flags & RT_FLAG_FULL_SCAN) == 0;
+#define RT_LAUNCH_TRACE(B, C, P) hipLaunchKernelGGL((trace_kernel<B, C, P>), grid, block, lds, c->stream, t)
+      if (!batched && cull && !profile) RT_LAUNCH_TRACE(false, true, false);
+      if (!batched && cull && profile) RT_LAUNCH_TRACE(false, true, true);
+      if (!batched && !cull && !profile) RT_LAUNCH_TRACE(false, false, false);
+      if (!batched && !cull && profile) RT_LAUNCH_TRACE(false, false, true);
+      if (batched && cull && !profile) RT_LAUNCH_TRACE(true, true, false);
+      if (batched && cull && profile) RT_LAUNCH_TRACE(true, true, true);
+      if (batched && !cull && !profile) RT_LAUNCH_TRACE(true, false, false);
+      if (batched && !cull && profile) RT_LAUNCH_TRACE(true, false, true);
+#undef RT_LAUNCH_TRACE
       RT_HIP(hipGetLastError());
     }
     RT_HIP(hipEventRecord(pairs[used].second, c->stream));
@@ -975,6 +1079,9 @@ int rt_ctx_destroy(rt_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->filter.release();
+  c->bounds.release();
+  c->orig.release();
+  c->round_real.release();
   c->exact.release();
   c->mat.release();
   c->rad_type.release();
@@ -1030,38 +1137,60 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
       return fail(RT_ERR_ARG, "unknown material type in sphere " + std::to_string(i));
   }
   RT_HIP(hipSetDevice(c->device));
-  const uint32_t n_pad = (uint32_t)((n + kDrainEvery - 1) / kDrainEvery * kDrainEvery);
-  std::vector<float4> filter(n_pad), exact(n), mat(n);
-  std::vector<float2> rad_type(n);
+  // scan order and group bounds (rt_cluster.h); everything below is in scan order
+  const rtcluster::Layout L = rtcluster::build_layout(spheres, n);
+  const uint32_t n_pad = L.n_scan;
+  static_assert(rtcluster::kGroup == kChunk, "one group per chunk");
+  if (n_pad > kMaxSpheres) return fail(RT_ERR_LIMIT, "too many spheres after padding");
+  std::vector<float4> filter(n_pad), exact(n_pad), mat(n_pad), bounds(n_pad / 8);
+  std::vector<float2> rad_type(n_pad);
+  std::vector<uint16_t> round_real(n_pad / 16);
   std::vector<FilterSphere> fs(n_pad);
-  for (size_t i = 0; i < n; ++i) {
+  for (uint32_t p = 0; p < n_pad; ++p) {
+    const uint32_t i = L.order[p];
+    if (i == 0xffffffffu) {   // pad: K' so large that b*b - a*K' is negative for any ray
+      fs[p] = FilterSphere{0.0f, 0.0f, 0.0f, 1.0e30f};
+      exact[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      mat[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      rad_type[p] = make_float2(1.0f, 0.0f);
+      continue;
+    }
     const rt_sphere &s = spheres[i];
-    fs[i] = make_filter_sphere(s.center[0], s.center[1], s.center[2], s.radius);
-    exact[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);  // c/main.c:219
-    mat[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
+    fs[p] = make_filter_sphere(s.center[0], s.center[1], s.center[2], s.radius);
+    exact[p] = make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);  // c/main.c:219
+    mat[p] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
     float type_bits;
     int32_t ty = s.type;
     std::memcpy(&type_bits, &ty, sizeof ty);
-    rad_type[i] = make_float2(s.radius, type_bits);
+    rad_type[p] = make_float2(s.radius, type_bits);
   }
-  // pads: K' so large that b*b - a*K' is negative for any ray
-  for (size_t i = n; i < n_pad; ++i) fs[i] = FilterSphere{0.0f, 0.0f, 0.0f, 1.0e30f};
-  // pair image: entries 2p, 2p+1 = {cx0,cx1,cy0,cy1}, {cz0,cz1,K'0,K'1} of spheres 2p, 2p+1
-  for (size_t p2 = 0; p2 < n_pad; p2 += 2) {
+  // pair images: entries 2p, 2p+1 = {x0,x1,y0,y1}, {z0,z1,K'0,K'1} of items 2p, 2p+1
+  for (uint32_t p2 = 0; p2 < n_pad; p2 += 2) {
     filter[p2] = make_float4(fs[p2].cx, fs[p2 + 1].cx, fs[p2].cy, fs[p2 + 1].cy);
     filter[p2 + 1] = make_float4(fs[p2].cz, fs[p2 + 1].cz, fs[p2].kprime, fs[p2 + 1].kprime);
   }
+  for (uint32_t g = 0; g < n_pad / 8; g += 2) {
+    const FilterSphere &b0 = L.bounds[g], &b1 = L.bounds[g + 1];
+    bounds[g] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
+    bounds[g + 1] = make_float4(b0.cz, b1.cz, b0.kprime, b1.kprime);
+    round_real[g / 2] = (uint16_t)(L.real_in_group[g] | (L.real_in_group[g + 1] << 8));
+  }
   int rc;
-  if ((rc = c->filter.reserve(n_pad)) || (rc = c->exact.reserve(n)) || (rc = c->mat.reserve(n)) ||
-      (rc = c->rad_type.reserve(n)))
+  if ((rc = c->filter.reserve(n_pad)) || (rc = c->bounds.reserve(n_pad / 8)) || (rc = c->exact.reserve(n_pad)) ||
+      (rc = c->mat.reserve(n_pad)) || (rc = c->rad_type.reserve(n_pad)) || (rc = c->orig.reserve(n_pad)) ||
+      (rc = c->round_real.reserve(n_pad / 16)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->exact.p, exact.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->mat.p, mat.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->rad_type.p, rad_type.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->bounds.p, bounds.data(), (n_pad / 8) * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->exact.p, exact.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->mat.p, mat.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->rad_type.p, rad_type.data(), n_pad * sizeof(float2), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint16_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
   c->n_pad = n_pad;
+  for (int d = 0; d < 3; ++d) c->bscale[d] = L.scale[d];
   return RT_OK;
 }
 
@@ -1146,6 +1275,8 @@ int rt_ctx_counters(rt_ctx *c, rt_counters *out, int reset) {
     out->cycles_shade = v[8];
     out->cycles_total = v[9];
     out->realtime_total = v[10];
+    out->own_groups = v[11];
+    out->wave_groups = v[12];
   }
   if (reset) RT_HIP(hipMemset(c->counters.p, 0, kNumCounters * sizeof(unsigned long long)));
   return RT_OK;
@@ -1167,9 +1298,9 @@ int rt_debug_closest_hit(rt_ctx *c, const float *rays, size_t n_rays, float tmin
   }
   hipError_t e = hipMemcpy(d_rays.p, rays, 6 * n_rays * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    size_t lds = (size_t)kMaxLdsSpheres * sizeof(float4) + (size_t)kListCap * kBlockThreads * sizeof(uint16_t);
+    size_t lds = scan_lds_bytes(kMaxLdsSpheres);
     uint32_t blocks = (uint32_t)((n_rays + kBlockThreads - 1) / kBlockThreads);
-    hipLaunchKernelGGL(closest_hit_kernel, dim3(blocks), dim3(kBlockThreads), lds, c->stream, scene_view(c), d_rays.p,
+    hipLaunchKernelGGL(closest_hit_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds, c->stream, scene_view(c), d_rays.p,
                        (uint32_t)n_rays, tmin, tmax, d_idx.p, d_t.p);
     e = hipGetLastError();
   }

@@ -55,6 +55,23 @@ def test_filter_has_no_false_negatives(core, rt, builder):
     assert passed.value < 1.35 * pos.value + 3 * len(rays)   # ... and the filter is not much looser
 
 
+@pytest.mark.parametrize("builder", ["small_scene", "random_scene", "glass_scene", "dense"])
+def test_group_culling_never_hides_a_candidate(core, rt, builder):
+    sc = rt.random_scene(100)[::7][:4000] if builder == "dense" else getattr(rt, builder)()
+    n_scan, n_groups = C.c_uint32(), C.c_uint32()
+    assert core.core_layout_check(vp(sc), C.c_size_t(len(sc)), C.byref(n_scan), C.byref(n_groups)) == 0
+    assert n_scan.value >= len(sc) and n_scan.value < len(sc) + 64 + len(sc) // 4
+    rng = np.random.default_rng(8)
+    rays = np.concatenate([random_rays(rng, 4000, sc), adversarial_rays(rng, sc, 8000)])
+    rays[::5, :3] *= 2.5          # some origins beyond the culling limit too
+    culled, groups = C.c_uint64(), C.c_uint64()
+    core.core_cull_check.restype = C.c_uint64
+    bad = core.core_cull_check(vp(sc), C.c_size_t(len(sc)), vp(rays), C.c_size_t(len(rays)), C.byref(culled), C.byref(groups))
+    assert bad == 0
+    if builder != "small_scene":
+        assert culled.value > 0.5 * groups.value          # and a single ray skips most groups
+
+
 def test_packed_filter_equals_scalar_filter(core, rt):
     sc = rt.random_scene()
     rays = random_rays(np.random.default_rng(5), 2000, sc)

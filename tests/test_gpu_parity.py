@@ -156,7 +156,7 @@ def test_full_size_properties(renderer, rt):
     out = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=1))
     c = renderer.counters(reset=True)
     assert c["paths"] == nx * ny * spp
-    assert c["tests"] == c["segments"] * len(sc)
+    assert c["tests"] <= c["segments"] * (len(sc) + len(sc) // 8 + 4)     # group culling: bounds + surviving groups
     assert c["segments"] >= c["paths"] and c["candidates"] >= c["segments"] * 0.5
     sky = out["first_hit"] == -1
     assert sky[:50].all() and not sky[-200:].any()
@@ -179,6 +179,24 @@ def test_wavefront_variant_is_bit_identical_to_the_megakernel(renderer, rt, scen
     for k in ("rgb8", "first_hit", "hit_sum"):
         assert np.array_equal(mega[k], wave[k]), k
     assert np.array_equal(mega["linear"].view(np.uint32), wave["linear"].view(np.uint32))
+
+
+@pytest.mark.parametrize("scene,nx,ny,spp", [("small_scene", 160, 90, 8), ("random_scene", 240, 135, 8), ("glass_scene", 160, 90, 8)])
+def test_group_culling_changes_nothing_but_the_test_count(renderer, rt, scene, nx, ny, spp):
+    """RT_FLAG_FULL_SCAN filters every sphere for every ray; the default skips groups no ray of the wave can touch."""
+    sc = getattr(rt, scene)()
+    renderer.upload(sc)
+    cam = rt.camera_default(nx, ny)
+    renderer.counters(reset=True)
+    full = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=4, flags=2))
+    c_full = renderer.counters(reset=True)
+    cull = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=4))
+    c_cull = renderer.counters(reset=True)
+    assert c_full["tests"] == c_full["segments"] * len(sc)
+    assert c_cull["segments"] == c_full["segments"] and c_cull["tests"] <= c_full["tests"] * 1.2
+    for k in ("rgb8", "first_hit", "hit_sum"):
+        assert np.array_equal(full[k], cull[k]), k
+    assert np.array_equal(full["linear"].view(np.uint32), cull["linear"].view(np.uint32))
 
 
 def psnr(a, b):

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported(rt):
 
 def test_struct_layouts(rt):
     assert C.sizeof(rt._native.RtCamera) == 88 and rt.SPHERE_DTYPE.itemsize == 36
-    assert C.sizeof(rt._native.RtJob) == 48 and C.sizeof(rt._native.RtCounters) == 88
+    assert C.sizeof(rt._native.RtJob) == 48 and C.sizeof(rt._native.RtCounters) == 104
 
 
 def test_host_inputs_match_oracle(rt, oracle):
