@@ -38,23 +38,24 @@ namespace {
 
 // ----------------------------------------------------------------- limits
 constexpr int kBlockThreads = 256;
-constexpr int kListCap = 32;          // pending candidates per lane
 constexpr int kChunk = 8;             // spheres per unrolled filter group
-constexpr int kDrainEvery = 16;       // spheres between overflow checks (<= kListCap/2)
+constexpr int kDrainEvery = 16;       // spheres per round of the scan (two groups)
 constexpr uint32_t kMaxLdsSpheres = 2048;  // 32 KiB of filter entries per staged batch
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
 constexpr int kNumCounters = 13;
 // squared origin distance up to which the group bounds are valid (rt_cluster.h), with a little room
 __device__ __forceinline__ constexpr float rtcluster_limit2() { return 1023.0f; }
 
-// All arrays are in SCAN order (rt_cluster.h): position -> sphere, pads included.
+// The scan's arrays are in SCAN order (rt_cluster.h): position -> sphere, pads included.
 struct DeviceScene {
   const float4 *filter;   // n_pad entries, sphere pairs {cx0,cx1,cy0,cy1},{cz0,cz1,K'0,K'1}; pads never pass
   const float4 *bounds;   // n_pad/8 entries, group-bound pairs in the same pair layout
   const float4 *exact;    // n_pad entries {cx, cy, cz, r*r}
-  const float4 *mat;      // n_pad entries {albedo rgb, param}
-  const float2 *rad_type; // n_pad entries {radius, type as float bits}
   const uint32_t *orig;   // n_pad entries: index in the caller's list (ties go to the lowest), ~0 for pads
+  // for shading, in the CALLER's order (n entries):
+  const float4 *geom_o;   // {cx, cy, cz, radius}
+  const float4 *mat_o;    // {albedo rgb, param}
+  const int32_t *type_o;  // material type
   const uint16_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (lo byte, hi byte)
   uint32_t n, n_pad;
   float bscale[3];        // axis factors (powers of two) of the space the group bounds live in
@@ -68,14 +69,11 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   return v;
 }
 
-// One closest-hit query for every lane of the workgroup, against filter
-// entries [0, count) in LDS that stand for global sphere indices base+i.
-// Lanes without a ray pass a FilterRay that can never pass (see dead_ray()).
+// Result of one closest-hit query of a lane.
 struct HitState {
-  float closest;    // smallest t so far
-  int index;        // its scan position, -1 for none
-  uint32_t orig;    // its index in the caller's list (0 while there is no hit, so that t == tmax is refused)
-  uint32_t cand;    // exact evaluations done
+  float closest;    // smallest t (the query's tmax while there is no hit)
+  int index;        // index of the sphere in the caller's list, -1 for none
+  uint32_t cand;    // exact evaluations this lane performed (for whichever ray)
   uint32_t tests;   // filter tests done (bounds and spheres; wave-uniform)
   uint32_t own_groups;   // groups this lane's own ray needed (diagnostic: what a per-ray cull would scan)
   uint32_t wave_groups;  // groups the wave scanned
@@ -91,29 +89,71 @@ __device__ __forceinline__ FilterRay dead_ray() {
   return f;
 }
 
-// Exact evaluation (c/main.c:214-236) of the listed spheres.  The reference's
-// shrinking-tmax scan returns the smallest first-root-in-(tmin, FLT_MAX) and,
-// among equal t, the lowest index; taking that minimum explicitly gives the
-// same hit in any evaluation order.
-__device__ __forceinline__ void drain_list(const DeviceScene &sc, const uint16_t *list, int &cnt, V3 A, V3 B, float a,
-                                           float tmin, HitState &h) {
-  for (int j = 0; wave_any(j < cnt); ++j) {
-    if (j < cnt) {
-      uint32_t pos = list[j * kBlockThreads];
-      float4 e = sc.exact[pos];
+// LDS carve-up shared by every kernel that scans.  Per workgroup: the pair
+// image of the resident batch and its group bounds; per lane: its ray (so that
+// any lane of the wave can evaluate a sphere for it) and its best hit as one
+// 64-bit key {t bits, sphere index}; per wave: the list of (lane, sphere)
+// pairs that passed the filter and await exact evaluation.
+constexpr uint32_t kWaveListCap = 1024;             // entries per wave
+constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a chunk adds at most 64*kChunk
+
+struct ScanLds {
+  float4 *pairs;
+  float4 *bounds;
+  float4 *rays;                  // 2 per lane: {A, a}, {B, tmin}
+  unsigned long long *best;      // 1 per lane
+  uint32_t *wlist;               // kWaveListCap per wave: (owner lane << 16) | scan position
+};
+
+__device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entries) {
+  ScanLds l;
+  l.pairs = reinterpret_cast<float4 *>(smem);
+  l.bounds = l.pairs + entries;
+  l.rays = l.bounds + entries / 8u;
+  l.best = reinterpret_cast<unsigned long long *>(l.rays + 2 * kBlockThreads);
+  l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
+  return l;
+}
+
+__device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
+                                            uint32_t tid) {
+  for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[i] = sc.filter[base + i];
+  for (uint32_t i = tid; i < count / 8u; i += kBlockThreads) lds.bounds[i] = sc.bounds[base / 8u + i];
+}
+
+// What a wave carries through one scan.
+struct WaveScan {
+  uint32_t *wlist;               // this wave's list
+  const float4 *rays;            // this wave's 64 rays (lane l at [2l], [2l+1])
+  unsigned long long *best;      // this wave's 64 keys
+  uint32_t wcnt;                 // entries in the list (wave-uniform)
+  uint32_t lane;
+};
+
+// Exact evaluation (c/main.c:214-236) of the listed (lane, sphere) pairs, 64
+// pairs at a time whichever lanes they belong to: a lane's candidates are few
+// (two on average) but unevenly spread, and this way the double-precision
+// roots are computed with every lane busy.  The reference's shrinking-tmax
+// scan returns the smallest first-root-in-(tmin, FLT_MAX) and, among equal t,
+// the lowest index; an LDS 64-bit atomic min on {t bits, index} takes exactly
+// that minimum in any order (t > tmin >= 0, so its bits order like its value).
+__device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, HitState &h) {
+  for (uint32_t e0 = 0; e0 < w.wcnt; e0 += 64u) {
+    const uint32_t e = e0 + w.lane;
+    if (e < w.wcnt) {
+      const uint32_t entry = w.wlist[e];
+      const uint32_t owner = entry >> 16, pos = entry & 0xffffu;
+      const float4 ra = w.rays[2 * owner], rb = w.rays[2 * owner + 1];
+      const float4 ex = sc.exact[pos];
       float t;
-      if (exact_hit(A, B, a, e.x, e.y, e.z, e.w, tmin, kFltMax, t)) {
-        uint32_t o = sc.orig[pos];
-        if (t < h.closest || (t == h.closest && o < h.orig)) {
-          h.closest = t;
-          h.index = (int)pos;
-          h.orig = o;
-        }
+      if (exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, ex.x, ex.y, ex.z, ex.w, rb.w, kFltMax, t)) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | sc.orig[pos];
+        atomicMin(&w.best[owner], key);
       }
+      h.cand++;
     }
   }
-  h.cand += (uint32_t)cnt;
-  cnt = 0;
+  w.wcnt = 0;
 }
 
 // One group of kChunk spheres = kChunk float4 of the pair image (see scan_batch).
@@ -126,10 +166,10 @@ __device__ __forceinline__ void load_chunk(ChunkRegs &r, const float4 *lds_pairs
   for (int u = 0; u < kChunk; ++u) r.q[u] = lds_pairs[first + u];
 }
 
-// filter the kChunk spheres held in r (global indices first_index..+kChunk-1)
-// and append the ones that pass to this lane's list
+// filter the kChunk spheres held in r (scan positions first_index..+kChunk-1)
+// and append the (lane, sphere) pairs that pass to the wave's list
 __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_index, const FilterRay2 &fr,
-                                             uint16_t *list, int &cnt) {
+                                             WaveScan &w) {
   f32x2 d[kChunk / 2];
 #pragma unroll
   for (int u = 0; u < kChunk / 2; ++u) {
@@ -152,10 +192,10 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
     for (int u = 0; u < kChunk; ++u) {
       if (m[u] != 0ull) {
         asm volatile("");
-        if (d[u >> 1][u & 1] > 0.0f) {
-          list[cnt * kBlockThreads] = (uint16_t)(first_index + u);
-          ++cnt;
-        }
+        const uint32_t rank =
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+        if (d[u >> 1][u & 1] > 0.0f) w.wlist[w.wcnt + rank] = (w.lane << 16) | (first_index + u);
+        w.wcnt += (uint32_t)__popcll(m[u]);
       }
     }
   }
@@ -176,19 +216,19 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
 // for) take every group.
 template <bool kCull>
 __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, const float4 *lds_bounds,
-                                           uint32_t base, uint32_t count, const FilterRay2 &fr, const FilterRay2 &frb, bool far,
-                                           uint16_t *list, int &cnt, V3 A, V3 B, float a, float tmin, HitState &h) {
+                                           uint32_t base, uint32_t count, const FilterRay2 &fr, const FilterRay2 &frb,
+                                           bool far, WaveScan &w, HitState &h) {
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
   if (!kCull) {
     ChunkRegs ra, rb;
     load_chunk(ra, lds_pairs, 0);
     for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
       load_chunk(rb, lds_pairs, i0 + kChunk);
-      filter_chunk(ra, base + i0, fr, list, cnt);
+      filter_chunk(ra, base + i0, fr, w);
       // the read past the end of the last round stays inside the image and is never used
       load_chunk(ra, lds_pairs, i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u);
-      filter_chunk(rb, base + i0 + kChunk, fr, list, cnt);
-      if (wave_any(cnt > kListCap - kDrainEvery)) drain_list(sc, list, cnt, A, B, a, tmin, h);
+      filter_chunk(rb, base + i0 + kChunk, fr, w);
+      if (w.wcnt > kWaveListFlush - 64u * kChunk) drain_wave(sc, w, h);
     }
     return;
   }
@@ -209,52 +249,31 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
       asm volatile("");
       ChunkRegs r;
       load_chunk(r, lds_pairs, i0);
-      filter_chunk(r, base + i0, fr, list, cnt);
+      filter_chunk(r, base + i0, fr, w);
       tests += real & 0xffu;
     }
     if (m1 != 0ull) {
       asm volatile("");
       ChunkRegs r;
       load_chunk(r, lds_pairs, i0 + kChunk);
-      filter_chunk(r, base + i0 + kChunk, fr, list, cnt);
+      filter_chunk(r, base + i0 + kChunk, fr, w);
       tests += real >> 8;
     }
     b0 = n0;
     b1 = n1;
-    if (wave_any(cnt > kListCap - kDrainEvery)) drain_list(sc, list, cnt, A, B, a, tmin, h);
+    if (w.wcnt > kWaveListFlush - 64u * kChunk) drain_wave(sc, w, h);
   }
   h.tests += tests;
 }
 
-// LDS carve-up shared by every kernel that scans: the pair image of the
-// resident batch, its group bounds, then the per-lane candidate lists.
-struct ScanLds {
-  float4 *pairs;
-  float4 *bounds;
-  uint16_t *list;
-};
-
-__device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entries) {
-  ScanLds l;
-  l.pairs = reinterpret_cast<float4 *>(smem);
-  l.bounds = l.pairs + entries;
-  l.list = reinterpret_cast<uint16_t *>(l.bounds + entries / 8u);
-  return l;
-}
-
-__device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
-                                            uint32_t tid) {
-  for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[i] = sc.filter[base + i];
-  for (uint32_t i = tid; i < count / 8u; i += kBlockThreads) lds.bounds[i] = sc.bounds[base / 8u + i];
-}
-
 // Closest hit of the ray (A, B) of every lane of the workgroup against the
-// whole scene.  Unbatched: the scene is already resident in LDS.  Batched: it
-// is streamed through LDS in kMaxLdsSpheres pieces, which needs every wave of
-// the workgroup here together.  Lanes without a ray pass dead_ray().
+// whole scene, within (tmin, tmax).  Unbatched: the scene is already resident
+// in LDS.  Batched: it is streamed through LDS in kMaxLdsSpheres pieces, which
+// needs every wave of the workgroup here together.  Lanes without a ray pass
+// dead_ray().
 template <bool kBatched, bool kCull>
 __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const ScanLds &lds, uint32_t tid, bool alive,
-                                                  V3 A, V3 B, float tmin, HitState &h) {
+                                                  V3 A, V3 B, float tmin, float tmax, HitState &h) {
   FilterRay fr1 = alive ? make_filter_ray(A, B) : dead_ray();
   const FilterRay2 fr = widen(fr1);
   // the same ray in the scaled space of the group bounds (power-of-two factors: exact products)
@@ -266,21 +285,37 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   const float a = dot(B, B);
   // origins beyond the radius the group bounds were derived for scan every group
   const bool far = alive && !(dot(A, A) < (float)(rtcluster_limit2()));
-  uint16_t *my_list = lds.list + tid;
-  int cnt = 0;
+  const uint32_t wave_first = tid & ~63u;
+  WaveScan w;
+  w.wlist = lds.wlist + (tid >> 6) * kWaveListCap;
+  w.rays = lds.rays + 2 * wave_first;
+  w.best = lds.best + wave_first;
+  w.wcnt = 0;
+  w.lane = tid & 63u;
+  // this lane's ray and "no hit yet" key where the other lanes of the wave can reach them; the
+  // key {tmax bits, 0} can only be undercut by t < tmax
+  lds.rays[2 * tid] = make_float4(A.x, A.y, A.z, a);
+  lds.rays[2 * tid + 1] = make_float4(B.x, B.y, B.z, tmin);
+  lds.best[tid] = (unsigned long long)__float_as_uint(tmax) << 32;
   if (kBatched) {
     for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
       uint32_t count = min(kMaxLdsSpheres, sc.n_pad - base);
       __syncthreads();
       stage_batch(sc, lds, base, count, tid);
       __syncthreads();
-      scan_batch<kCull>(sc, lds.pairs, lds.bounds, base, count, fr, frb, far, my_list, cnt, A, B, a, tmin, h);
+      scan_batch<kCull>(sc, lds.pairs, lds.bounds, base, count, fr, frb, far, w, h);
     }
   } else {
-    scan_batch<kCull>(sc, lds.pairs, lds.bounds, 0u, sc.n_pad, fr, frb, far, my_list, cnt, A, B, a, tmin, h);
+    scan_batch<kCull>(sc, lds.pairs, lds.bounds, 0u, sc.n_pad, fr, frb, far, w, h);
   }
   if (!kCull) h.tests += sc.n;
-  drain_list(sc, my_list, cnt, A, B, a, tmin, h);
+  drain_wave(sc, w, h);
+  const unsigned long long key = lds.best[tid];
+  const float t = __uint_as_float((uint32_t)(key >> 32));
+  if (alive && t < tmax) {
+    h.closest = t;
+    h.index = (int)(uint32_t)key;
+  }
 }
 
 // global row of compact (tile-major) local row lr
@@ -407,8 +442,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
       n_live += (unsigned long long)__popcll(__ballot(alive));
       c0 = __builtin_amdgcn_s_memtime();
     }
-    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u};
-    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, job.tmin, h);
+    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u};
+    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
     if (kProfile) c1 = c2 = __builtin_amdgcn_s_memtime();
 
     // ---- (3): shade
@@ -421,15 +456,14 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
         n_wave += h.wave_groups;
       }
       bool done = false;
-      if (depth == 0) first_hit = h.index >= 0 ? (int32_t)h.orig : -1;
+      if (depth == 0) first_hit = h.index;
       if (h.index >= 0) {
-        float4 e = sc.exact[h.index];
-        float4 m4 = sc.mat[h.index];
-        float2 rt = sc.rad_type[h.index];
+        float4 e = sc.geom_o[h.index];
+        float4 m4 = sc.mat_o[h.index];
         V3 ctr = v3(e.x, e.y, e.z);
         V3 p = A + h.closest * B;              // c/structs.c:6-8
-        V3 n = (p - ctr) / rt.x;               // c/main.c:229
-        Material m{__float_as_int(rt.y), v3(m4.x, m4.y, m4.z), m4.w};
+        V3 n = (p - ctr) / e.w;                // c/main.c:229
+        Material m{sc.type_o[h.index], v3(m4.x, m4.y, m4.z), m4.w};
         V3 atten, nA, nB;
         if (scatter(m, A, B, p, n, g, atten, nA, nB)) {
           A = nA;
@@ -649,14 +683,14 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
       A = v3(o.x, o.y, o.z);
       B = v3(d.x, d.y, d.z);
     }
-    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u};
-    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, args.job.tmin, h);
+    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u};
+    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, args.job.tmin, kFltMax, h);
     if (alive) {
       // queue 0 = sky, 1 + material type otherwise
-      q[sub] = h.index < 0 ? 0 : 1 + __float_as_int(sc.rad_type[h.index].y);
+      q[sub] = h.index < 0 ? 0 : 1 + sc.type_o[h.index];
       pos[sub] = atomicAdd(&qcnt[q[sub]], 1u);
       pool.org[slot].w = h.closest;
-      pool.dir[slot].w = __int_as_float(h.index);      // scan position
+      pool.dir[slot].w = __int_as_float(h.index);
       n_seg++;
       n_cand += h.cand;
       n_tests += h.tests;
@@ -698,16 +732,15 @@ __global__ __launch_bounds__(kBlockThreads) void wf_shade(const TraceArgs args, 
     V3 A = v3(o.x, o.y, o.z), B = v3(d.x, d.y, d.z), color = v3(c4.x, c4.y, c4.z);
     const int index = __float_as_int(d.w);
     int first_hit = __float_as_int(c4.w);
-    if (mi.z == 0u) first_hit = index >= 0 ? (int)args.sc.orig[index] : -1;
+    if (mi.z == 0u) first_hit = index;
     if (Q == 0) {
       color = color * sky(B);                    // c/main.c:274-279
       finished = true;
     } else {
-      const float4 e = args.sc.exact[index];
-      const float4 m4 = args.sc.mat[index];
-      const float radius = args.sc.rad_type[index].x;
+      const float4 e = args.sc.geom_o[index];
+      const float4 m4 = args.sc.mat_o[index];
       V3 p = A + o.w * B;
-      V3 n = (p - v3(e.x, e.y, e.z)) / radius;
+      V3 n = (p - v3(e.x, e.y, e.z)) / e.w;
       Material m{Q - 1, v3(m4.x, m4.y, m4.z), m4.w};
       Rng g{mi.x, mi.y};
       V3 atten, nA, nB;
@@ -760,10 +793,10 @@ __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene 
     A = v3(rays[6 * r + 0], rays[6 * r + 1], rays[6 * r + 2]);
     B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
   }
-  HitState h{tmax, -1, 0u, 0u, 0u, 0u, 0u};
-  closest_hit_scene<true, kCull>(sc, lds, tid, alive, A, B, tmin, h);
+  HitState h{tmax, -1, 0u, 0u, 0u, 0u};
+  closest_hit_scene<true, kCull>(sc, lds, tid, alive, A, B, tmin, tmax, h);
   if (alive) {
-    index[r] = h.index >= 0 ? (int32_t)sc.orig[h.index] : -1;
+    index[r] = h.index;
     t[r] = h.index >= 0 ? h.closest : 0.0f;
   }
 }
@@ -825,8 +858,8 @@ struct rt_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events[kHistory];
   int trace_used[kHistory] = {};
   long renders = 0;
-  DevBuf<float4> filter, bounds, exact, mat;
-  DevBuf<float2> rad_type;
+  DevBuf<float4> filter, bounds, exact, geom_o, mat_o;
+  DevBuf<int32_t> type_o;
   DevBuf<uint32_t> orig;
   DevBuf<uint16_t> round_real;
   uint32_t n = 0, n_pad = 0;
@@ -857,6 +890,7 @@ int check_job(const rt_job *job) {
   if (job->row0 >= job->ny) return fail(RT_ERR_ARG, "row0 outside the image");
   if (job->nsamples == 0) return fail(RT_ERR_ARG, "nsamples is zero");
   if (job->max_depth == 0) return fail(RT_ERR_ARG, "max_depth is zero");
+  if (!(job->tmin >= 0.0f)) return fail(RT_ERR_ARG, "tmin must be >= 0");
   if ((uint64_t)job->nx * job->ny > 0xffffffffull) return fail(RT_ERR_LIMIT, "more than 2^32 pixels");
   if (job->kernel != RT_KERNEL_MEGA && job->kernel != RT_KERNEL_WAVEFRONT)
     return fail(RT_ERR_ARG, "unknown kernel variant");
@@ -864,13 +898,14 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->bounds.p, c->exact.p, c->mat.p, c->rad_type.p, c->orig.p, c->round_real.p, c->n, c->n_pad,
+  return DeviceScene{c->filter.p, c->bounds.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->round_real.p, c->n, c->n_pad,
                      {c->bscale[0], c->bscale[1], c->bscale[2]}};
 }
 
 size_t scan_lds_bytes(uint32_t entries) {
-  return (size_t)entries * sizeof(float4) + (size_t)(entries / 8u) * sizeof(float4) +
-         (size_t)kListCap * kBlockThreads * sizeof(uint16_t);
+  return (size_t)entries * sizeof(float4) + (size_t)(entries / 8u) * sizeof(float4) +      // pair image, bounds
+         (size_t)2 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
+         (size_t)(kBlockThreads / 64) * kWaveListCap * sizeof(uint32_t);                    // wave lists
 }
 size_t trace_lds_bytes(uint32_t n_pad) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres); }
 
@@ -1083,8 +1118,9 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->orig.release();
   c->round_real.release();
   c->exact.release();
-  c->mat.release();
-  c->rad_type.release();
+  c->geom_o.release();
+  c->mat_o.release();
+  c->type_o.release();
   c->counters.release();
   c->queue.release();
   c->rad.release();
@@ -1142,27 +1178,26 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   const uint32_t n_pad = L.n_scan;
   static_assert(rtcluster::kGroup == kChunk, "one group per chunk");
   if (n_pad > kMaxSpheres) return fail(RT_ERR_LIMIT, "too many spheres after padding");
-  std::vector<float4> filter(n_pad), exact(n_pad), mat(n_pad), bounds(n_pad / 8);
-  std::vector<float2> rad_type(n_pad);
+  std::vector<float4> filter(n_pad), exact(n_pad), bounds(n_pad / 8), geom_o(n), mat_o(n);
+  std::vector<int32_t> type_o(n);
   std::vector<uint16_t> round_real(n_pad / 16);
   std::vector<FilterSphere> fs(n_pad);
+  for (size_t i = 0; i < n; ++i) {
+    const rt_sphere &s = spheres[i];
+    geom_o[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius);
+    mat_o[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
+    type_o[i] = s.type;
+  }
   for (uint32_t p = 0; p < n_pad; ++p) {
     const uint32_t i = L.order[p];
     if (i == 0xffffffffu) {   // pad: K' so large that b*b - a*K' is negative for any ray
       fs[p] = FilterSphere{0.0f, 0.0f, 0.0f, 1.0e30f};
       exact[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      mat[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      rad_type[p] = make_float2(1.0f, 0.0f);
       continue;
     }
     const rt_sphere &s = spheres[i];
     fs[p] = make_filter_sphere(s.center[0], s.center[1], s.center[2], s.radius);
     exact[p] = make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);  // c/main.c:219
-    mat[p] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
-    float type_bits;
-    int32_t ty = s.type;
-    std::memcpy(&type_bits, &ty, sizeof ty);
-    rad_type[p] = make_float2(s.radius, type_bits);
   }
   // pair images: entries 2p, 2p+1 = {x0,x1,y0,y1}, {z0,z1,K'0,K'1} of items 2p, 2p+1
   for (uint32_t p2 = 0; p2 < n_pad; p2 += 2) {
@@ -1177,15 +1212,16 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   }
   int rc;
   if ((rc = c->filter.reserve(n_pad)) || (rc = c->bounds.reserve(n_pad / 8)) || (rc = c->exact.reserve(n_pad)) ||
-      (rc = c->mat.reserve(n_pad)) || (rc = c->rad_type.reserve(n_pad)) || (rc = c->orig.reserve(n_pad)) ||
-      (rc = c->round_real.reserve(n_pad / 16)))
+      (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
+      (rc = c->orig.reserve(n_pad)) || (rc = c->round_real.reserve(n_pad / 16)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->bounds.p, bounds.data(), (n_pad / 8) * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->exact.p, exact.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->mat.p, mat.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->rad_type.p, rad_type.data(), n_pad * sizeof(float2), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->geom_o.p, geom_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->type_o.p, type_o.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint16_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
@@ -1288,6 +1324,7 @@ int rt_debug_closest_hit(rt_ctx *c, const float *rays, size_t n_rays, float tmin
   if (c->n == 0) return fail(RT_ERR_NO_SCENE, "no scene uploaded");
   if (n_rays == 0) return RT_OK;
   if (n_rays > 0x7fffffffu) return fail(RT_ERR_LIMIT, "too many rays");
+  if (!(tmin >= 0.0f) || !(tmax > tmin)) return fail(RT_ERR_ARG, "need 0 <= tmin < tmax");
   RT_HIP(hipSetDevice(c->device));
   DevBuf<float> d_rays, d_t;
   DevBuf<int32_t> d_idx;
