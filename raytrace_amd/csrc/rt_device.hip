@@ -73,10 +73,11 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 struct HitState {
   float closest;    // smallest t (the query's tmax while there is no hit)
   int index;        // index of the sphere in the caller's list, -1 for none
-  uint32_t cand;    // exact evaluations this lane performed (for whichever ray)
-  uint32_t tests;   // filter tests done (bounds and spheres; wave-uniform)
+  uint32_t cand;    // exact evaluations the wave performed (wave-uniform)
+  uint32_t tests;   // filter tests done per ray (bounds and spheres; wave-uniform)
   uint32_t own_groups;   // groups this lane's own ray needed (diagnostic: what a per-ray cull would scan)
   uint32_t wave_groups;  // groups the wave scanned
+  unsigned long long drain_cycles;   // shader cycles in the closing drain (profiling builds only)
 };
 
 __device__ __forceinline__ FilterRay dead_ray() {
@@ -150,10 +151,102 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | sc.orig[pos];
         atomicMin(&w.best[owner], key);
       }
-      h.cand++;
     }
   }
+  h.cand += w.wcnt;
   w.wcnt = 0;
+}
+
+// The nine per-ray coefficients of the filter packed two to a register pair.
+// v_pk_fma_f32 can take either half of a pair for both of its lanes (op_sel /
+// op_sel_hi), so a coefficient that is the same for both spheres of a pair
+// needs one register, not a splat pair: 10 VGPRs per ray instead of 18.
+struct FilterRayP {
+  f32x2 p0;  // {-Bx, -By}
+  f32x2 p1;  // {-Bz, A.B}
+  f32x2 p2;  // {-2Ax, -2Ay}
+  f32x2 p3;  // {-2Az, -(B.B)}
+  f32x2 p4;  // {-(B.B)(A.A)(1-kappa), unused}
+};
+
+__device__ __forceinline__ FilterRayP pack_ray(const FilterRay &f) {
+  FilterRayP r;
+  r.p0 = f32x2{f.nbx, f.nby};
+  r.p1 = f32x2{f.nbz, f.ab};
+  r.p2 = f32x2{f.m2ax, f.m2ay};
+  r.p3 = f32x2{f.m2az, f.na};
+  r.p4 = f32x2{f.naaa, 0.0f};
+  return r;
+}
+
+// filter_discriminant2 (rt_core.h) for ONE sphere pair, same eight fused
+// multiply-adds in the same order, hence the same bits; cx..kp are the pair's
+// {sphere 0, sphere 1} values.
+#define RT_BCAST_LO_S0 "op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+#define RT_BCAST_HI_S0 "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+__device__ __forceinline__ f32x2 filter_pair(const FilterRayP &f, f32x2 cx, f32x2 cy, f32x2 cz, f32x2 kp) {
+  f32x2 d, t;
+  asm("v_pk_fma_f32 %0, %2, %8, %2 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"   // b  = -Bz*cz + A.B
+      "v_pk_fma_f32 %1, %4, %8, %9 " RT_BCAST_LO_S0 "\n\t"                 // c0 = -2Az*cz + K'
+      "v_pk_fma_f32 %0, %3, %7, %0 " RT_BCAST_HI_S0 "\n\t"                 // b += -By*cy
+      "v_pk_fma_f32 %1, %5, %7, %1 " RT_BCAST_HI_S0 "\n\t"                 // c0 += -2Ay*cy
+      "v_pk_fma_f32 %0, %3, %6, %0 " RT_BCAST_LO_S0 "\n\t"                 // b += -Bx*cx
+      "v_pk_fma_f32 %1, %5, %6, %1 " RT_BCAST_LO_S0 "\n\t"                 // c0 += -2Ax*cx
+      "s_nop 0\n\t"
+      "v_pk_fma_f32 %0, %0, %0, %10 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"  // d = b*b + naaa
+      "s_nop 0\n\t"
+      "v_pk_fma_f32 %0, %4, %1, %0 " RT_BCAST_HI_S0                        // d += -(B.B)*c0
+      : "=&v"(d), "=&v"(t)
+      : "v"(f.p1), "v"(f.p0), "v"(f.p3), "v"(f.p2), "v"(cx), "v"(cy), "v"(cz), "v"(kp), "v"(f.p4));
+  return d;
+}
+
+// The same for the four pairs of a chunk in one block, the eight chains
+// interleaved so that no instruction waits on the one before it.
+__device__ __forceinline__ void filter_four_pairs(const FilterRayP &f, const float4 (&q)[8], f32x2 (&d)[4]) {
+  f32x2 t0, t1, t2, t3;
+  const f32x2 cx0 = {q[0].x, q[0].y}, cy0 = {q[0].z, q[0].w}, cz0 = {q[1].x, q[1].y}, kp0 = {q[1].z, q[1].w};
+  const f32x2 cx1 = {q[2].x, q[2].y}, cy1 = {q[2].z, q[2].w}, cz1 = {q[3].x, q[3].y}, kp1 = {q[3].z, q[3].w};
+  const f32x2 cx2 = {q[4].x, q[4].y}, cy2 = {q[4].z, q[4].w}, cz2 = {q[5].x, q[5].y}, kp2 = {q[5].z, q[5].w};
+  const f32x2 cx3 = {q[6].x, q[6].y}, cy3 = {q[6].z, q[6].w}, cz3 = {q[7].x, q[7].y}, kp3 = {q[7].z, q[7].w};
+  asm("v_pk_fma_f32 %0, %8, %15, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %8, %19, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %2, %8, %23, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %3, %8, %27, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %4, %10, %15, %16 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %5, %10, %19, %20 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %6, %10, %23, %24 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %7, %10, %27, %28 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %0, %9, %14, %0 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %1, %9, %18, %1 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %2, %9, %22, %2 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %3, %9, %26, %3 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %4, %11, %14, %4 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %5, %11, %18, %5 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %6, %11, %22, %6 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %7, %11, %26, %7 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %0, %9, %13, %0 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %1, %9, %17, %1 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %2, %9, %21, %2 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %3, %9, %25, %3 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %4, %11, %13, %4 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %5, %11, %17, %5 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %6, %11, %21, %6 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %7, %11, %25, %7 " RT_BCAST_LO_S0 "\n\t"
+      "v_pk_fma_f32 %0, %0, %0, %12 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %1, %12 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %2, %2, %2, %12 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %3, %3, %3, %12 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %0, %10, %4, %0 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %1, %10, %5, %1 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %2, %10, %6, %2 " RT_BCAST_HI_S0 "\n\t"
+      "v_pk_fma_f32 %3, %10, %7, %3 " RT_BCAST_HI_S0
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(f.p1), "v"(f.p0), "v"(f.p3), "v"(f.p2), "v"(f.p4),             // %8 .. %12
+        "v"(cx0), "v"(cy0), "v"(cz0), "v"(kp0),                            // %13 .. %16
+        "v"(cx1), "v"(cy1), "v"(cz1), "v"(kp1),                            // %17 .. %20
+        "v"(cx2), "v"(cy2), "v"(cz2), "v"(kp2),                            // %21 .. %24
+        "v"(cx3), "v"(cy3), "v"(cz3), "v"(kp3));                           // %25 .. %28
 }
 
 // One group of kChunk spheres = kChunk float4 of the pair image (see scan_batch).
@@ -168,18 +261,10 @@ __device__ __forceinline__ void load_chunk(ChunkRegs &r, const float4 *lds_pairs
 
 // filter the kChunk spheres held in r (scan positions first_index..+kChunk-1)
 // and append the (lane, sphere) pairs that pass to the wave's list
-__device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_index, const FilterRay2 &fr,
+__device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_index, const FilterRayP &fr,
                                              WaveScan &w) {
   f32x2 d[kChunk / 2];
-#pragma unroll
-  for (int u = 0; u < kChunk / 2; ++u) {
-    const float4 q0 = r.q[2 * u], q1 = r.q[2 * u + 1];
-    f32x2 cx = {q0.x, q0.y}, cy = {q0.z, q0.w}, cz = {q1.x, q1.y}, kp = {q1.z, q1.w};
-    d[u] = filter_discriminant2(fr, cx, cy, cz, kp);
-  }
-  // keep the four FMA chains together (interleaved, no dependent back-to-back
-  // issue) instead of letting each sink next to its compare
-  asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+  filter_four_pairs(fr, r.q, d);
   // Eight compares into eight scalar masks, OR-ed on the scalar unit, one branch
   // for the whole chunk: no branch waits on a vector compare of its own.
   unsigned long long m[kChunk];
@@ -216,7 +301,7 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
 // for) take every group.
 template <bool kCull>
 __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, const float4 *lds_bounds,
-                                           uint32_t base, uint32_t count, const FilterRay2 &fr, const FilterRay2 &frb,
+                                           uint32_t base, uint32_t count, const FilterRayP &fr, const FilterRayP &frb,
                                            bool far, WaveScan &w, HitState &h) {
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
   if (!kCull) {
@@ -239,7 +324,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     const uint32_t nr = (i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u) >> 3;   // next round's bounds
     const float4 n0 = lds_bounds[nr], n1 = lds_bounds[nr + 1];
     f32x2 bx = {b0.x, b0.y}, by = {b0.z, b0.w}, bz = {b1.x, b1.y}, bk = {b1.z, b1.w};
-    const f32x2 db = filter_discriminant2(frb, bx, by, bz, bk);
+    const f32x2 db = filter_pair(frb, bx, by, bz, bk);
     const unsigned long long m0 = __ballot(db[0] > 0.0f) | far_mask, m1 = __ballot(db[1] > 0.0f) | far_mask;
     const uint32_t real = sc.round_real[(base + i0) >> 4];
     tests += 2u;
@@ -271,16 +356,15 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
 // in LDS.  Batched: it is streamed through LDS in kMaxLdsSpheres pieces, which
 // needs every wave of the workgroup here together.  Lanes without a ray pass
 // dead_ray().
-template <bool kBatched, bool kCull>
+template <bool kBatched, bool kCull, bool kProfile = false>
 __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const ScanLds &lds, uint32_t tid, bool alive,
                                                   V3 A, V3 B, float tmin, float tmax, HitState &h) {
-  FilterRay fr1 = alive ? make_filter_ray(A, B) : dead_ray();
-  const FilterRay2 fr = widen(fr1);
+  const FilterRayP fr = pack_ray(alive ? make_filter_ray(A, B) : dead_ray());
   // the same ray in the scaled space of the group bounds (power-of-two factors: exact products)
-  FilterRay2 frb = fr;
+  FilterRayP frb = fr;
   if (kCull) {
     const V3 sc3 = v3(sc.bscale[0], sc.bscale[1], sc.bscale[2]);
-    frb = widen(alive ? make_filter_ray(sc3 * A, sc3 * B) : dead_ray());
+    frb = pack_ray(alive ? make_filter_ray(sc3 * A, sc3 * B) : dead_ray());
   }
   const float a = dot(B, B);
   // origins beyond the radius the group bounds were derived for scan every group
@@ -309,7 +393,9 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
     scan_batch<kCull>(sc, lds.pairs, lds.bounds, 0u, sc.n_pad, fr, frb, far, w, h);
   }
   if (!kCull) h.tests += sc.n;
+  const unsigned long long d0 = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
   drain_wave(sc, w, h);
+  if (kProfile) h.drain_cycles = __builtin_amdgcn_s_memtime() - d0;
   const unsigned long long key = lds.best[tid];
   const float t = __uint_as_float((uint32_t)(key >> 32));
   if (alive && t < tmax) {
@@ -380,8 +466,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
   int32_t first_hit = -1;
   V3 A = v3(0, 0, 0), B = v3(0, 0, 1), color = v3(1, 1, 1);
   Rng g{0u, 0u};
-  uint32_t n_seg = 0, n_cand = 0, n_paths = 0;   // per lane; far below 2^32
-  unsigned long long n_tests = 0, n_own = 0, n_wave = 0;
+  // event counts of the wave, kept on the scalar unit (ballot popcounts and wave-uniform values)
+  unsigned long long n_seg = 0, n_cand = 0, n_paths = 0, n_tests = 0;
+  unsigned long long n_own = 0, n_wave = 0;   // per lane, profiling builds only
   unsigned long long c_scan = 0, c_drain = 0, c_shade = 0, n_iter = 0, n_live = 0;
   const unsigned long long c_begin = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long r_begin = kProfile ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -442,15 +529,22 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
       n_live += (unsigned long long)__popcll(__ballot(alive));
       c0 = __builtin_amdgcn_s_memtime();
     }
-    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u};
-    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
-    if (kProfile) c1 = c2 = __builtin_amdgcn_s_memtime();
+    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0ull};
+    closest_hit_scene<kBatched, kCull, kProfile>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
+    if (kProfile) {
+      c2 = __builtin_amdgcn_s_memtime();
+      c1 = c2 - h.drain_cycles;
+    }
 
     // ---- (3): shade
-    if (alive) {
-      n_seg++;
+    {
+      const uint32_t live = (uint32_t)__popcll(__ballot(alive));
+      n_seg += live;
       n_cand += h.cand;
-      n_tests += h.tests;
+      n_tests += (unsigned long long)h.tests * live;
+    }
+    bool finished = false;
+    if (alive) {
       if (kProfile) {
         n_own += h.own_groups;
         n_wave += h.wave_groups;
@@ -483,10 +577,11 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
       }
       if (done) {
         args.rad[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
-        n_paths++;
+        finished = true;
         alive = false;
       }
     }
+    n_paths += (unsigned long long)__popcll(__ballot(finished));
     if (kProfile) {
       unsigned long long c3 = __builtin_amdgcn_s_memtime();
       c_scan += c1 - c0;
@@ -512,13 +607,11 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
     }
   }
   // event counts: one atomic per wave and counter
-  unsigned long long w_paths = wave_sum((unsigned long long)n_paths), w_seg = wave_sum((unsigned long long)n_seg),
-                     w_cand = wave_sum((unsigned long long)n_cand), w_tests = wave_sum(n_tests);
   if (lane == 0 && args.counters) {
-    atomicAdd(&args.counters[0], w_paths);
-    atomicAdd(&args.counters[1], w_seg);
-    atomicAdd(&args.counters[2], w_tests);
-    atomicAdd(&args.counters[3], w_cand);
+    atomicAdd(&args.counters[0], n_paths);
+    atomicAdd(&args.counters[1], n_seg);
+    atomicAdd(&args.counters[2], n_tests);
+    atomicAdd(&args.counters[3], n_cand);
   }
 }
 
@@ -664,8 +757,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
   __syncthreads();
   int q[kWfSub];
   uint32_t pos[kWfSub];
-  uint32_t n_seg = 0, n_cand = 0;
-  unsigned long long n_tests = 0;
+  unsigned long long n_seg = 0, n_cand = 0, n_tests = 0;   // of the wave (wave-uniform)
 #pragma unroll 1
   for (int sub = 0; sub < kWfSub; ++sub) {
     const uint32_t slot = blockIdx.x * kWfPerBlock + sub * kBlockThreads + tid;
@@ -685,15 +777,18 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
     }
     HitState h{kFltMax, -1, 0u, 0u, 0u, 0u};
     closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, args.job.tmin, kFltMax, h);
+    {
+      const uint32_t live = (uint32_t)__popcll(__ballot(alive));
+      n_seg += live;
+      n_cand += h.cand;
+      n_tests += (unsigned long long)h.tests * live;
+    }
     if (alive) {
       // queue 0 = sky, 1 + material type otherwise
       q[sub] = h.index < 0 ? 0 : 1 + sc.type_o[h.index];
       pos[sub] = atomicAdd(&qcnt[q[sub]], 1u);
       pool.org[slot].w = h.closest;
       pool.dir[slot].w = __int_as_float(h.index);
-      n_seg++;
-      n_cand += h.cand;
-      n_tests += h.tests;
     }
   }
   __syncthreads();
@@ -706,12 +801,10 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
       pool.qlist[(size_t)q[sub] * pool.slots + qbase[q[sub]] + pos[sub]] = slot;
     }
   }
-  unsigned long long w_seg = wave_sum((unsigned long long)n_seg), w_cand = wave_sum((unsigned long long)n_cand),
-                     w_tests = wave_sum(n_tests);
-  if (lane == 0 && args.counters && w_seg) {
-    atomicAdd(&args.counters[1], w_seg);
-    atomicAdd(&args.counters[2], w_tests);
-    atomicAdd(&args.counters[3], w_cand);
+  if (lane == 0 && args.counters && n_seg) {
+    atomicAdd(&args.counters[1], n_seg);
+    atomicAdd(&args.counters[2], n_tests);
+    atomicAdd(&args.counters[3], n_cand);
   }
 }
 
