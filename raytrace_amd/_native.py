@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
-DEVICE_LIB = os.path.join(_LIB_DIR, "libraytrace_amd.so")
+# RT_AMD_DEVICE_LIB: another build of the same library (kernel experiments); it must exist
+DEVICE_LIB = os.environ.get("RT_AMD_DEVICE_LIB") or os.path.join(_LIB_DIR, "libraytrace_amd.so")
 HOST_LIB = os.path.join(_LIB_DIR, "libraytrace_host.so")
 
 SPHERE_DTYPE = np.dtype(

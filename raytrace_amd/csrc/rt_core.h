@@ -240,9 +240,27 @@ RT_HD f32x2 filter_discriminant2(const FilterRay2 &f, f32x2 cx, f32x2 cy, f32x2 
 
 // ------------------------------------------------------------ exact hit test
 
+// x / da, correctly rounded, for a divisor that is a float widened to double,
+// given r = 1.0 / da (correctly rounded).  q0 = RN(x r) is within 2^-52 of the
+// quotient; its residual e0 = x - q0 da is exact in double because da has only
+// 24 significant bits; q0 + e0 r is then within 2^-105 (relative) of x / da,
+// and a quotient of a double by a 24-bit divisor is either exact or at least
+// 2^-78 (relative) away from every rounding boundary, so rounding that sum
+// gives RN(x / da).  Three operations instead of a division per root
+// (c/main.c:220, 231 divide by the same `a` for every sphere a ray meets).
+// Infinite or NaN operands give NaN where the division gives an infinity; the
+// range test that follows fails for both.
+RT_HD double div_by_widened_float(double x, double da, double r) {
+  double q0 = x * r;
+  double e0 = __builtin_fma(-q0, da, x);
+  return __builtin_fma(e0, r, q0);
+}
+
 // c/main.c:214-236 for one sphere.  r2 = radius*radius (a float product, as
-// the reference forms it).  On a hit inside (tmin, tmax) returns true and t.
-RT_HD bool exact_hit(V3 A, V3 B, float a, float cx, float cy, float cz, float r2, float tmin, float tmax, float &t) {
+// the reference forms it); inv_a = 1.0 / (double)a.  On a hit inside
+// (tmin, tmax) returns true and t.
+RT_HD bool exact_hit(V3 A, V3 B, float a, double inv_a, float cx, float cy, float cz, float r2, float tmin, float tmax,
+                     float &t) {
   V3 oc = A - v3(cx, cy, cz);
   float b = dot(oc, B);
   float c = dot(oc, oc) - r2;
@@ -250,9 +268,9 @@ RT_HD bool exact_hit(V3 A, V3 B, float a, float cx, float cy, float cz, float r2
   if (D > 0.0f) {
     double root = __builtin_sqrt((double)D);
     double nb = (double)(-b), da = (double)a;
-    float t0 = (float)((nb - root) / da);
+    float t0 = (float)div_by_widened_float(nb - root, da, inv_a);
     if (tmin < t0 && t0 < tmax) { t = t0; return true; }
-    float t1 = (float)((nb + root) / da);
+    float t1 = (float)div_by_widened_float(nb + root, da, inv_a);
     if (tmin < t1 && t1 < tmax) { t = t1; return true; }
   }
   return false;

@@ -34,6 +34,17 @@
 
 using namespace rtcore;
 
+// RT_EXP: timing experiments that run one part of the scan twice (same results, the extra time is that
+// part's cost); 0 in every real build
+#ifndef RT_EXP
+#define RT_EXP 0
+#endif
+#if RT_EXP
+#define RT_ASM asm volatile   // so that the repeated block is not merged with the first
+#else
+#define RT_ASM asm
+#endif
+
 namespace {
 
 // ----------------------------------------------------------------- limits
@@ -101,7 +112,7 @@ constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a chunk ad
 struct ScanLds {
   float4 *pairs;
   float4 *bounds;
-  float4 *rays;                  // 2 per lane: {A, a}, {B, tmin}
+  float4 *rays;                  // 3 per lane: {A, a}, {B, tmin}, {1/a as a double, -, -}
   unsigned long long *best;      // 1 per lane
   uint32_t *wlist;               // kWaveListCap per wave: (owner lane << 16) | scan position
 };
@@ -111,7 +122,7 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
   l.pairs = reinterpret_cast<float4 *>(smem);
   l.bounds = l.pairs + entries;
   l.rays = l.bounds + entries / 8u;
-  l.best = reinterpret_cast<unsigned long long *>(l.rays + 2 * kBlockThreads);
+  l.best = reinterpret_cast<unsigned long long *>(l.rays + 3 * kBlockThreads);
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
   return l;
 }
@@ -125,7 +136,7 @@ __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds
 // What a wave carries through one scan.
 struct WaveScan {
   uint32_t *wlist;               // this wave's list
-  const float4 *rays;            // this wave's 64 rays (lane l at [2l], [2l+1])
+  const float4 *rays;            // this wave's 64 rays (lane l at [3l] .. [3l+2])
   unsigned long long *best;      // this wave's 64 keys
   uint32_t wcnt;                 // entries in the list (wave-uniform)
   uint32_t lane;
@@ -139,15 +150,19 @@ struct WaveScan {
 // the lowest index; an LDS 64-bit atomic min on {t bits, index} takes exactly
 // that minimum in any order (t > tmin >= 0, so its bits order like its value).
 __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, HitState &h) {
+#if RT_EXP == 11
+  for (int rep = 0; rep < 2; ++rep)
+#endif
   for (uint32_t e0 = 0; e0 < w.wcnt; e0 += 64u) {
     const uint32_t e = e0 + w.lane;
     if (e < w.wcnt) {
       const uint32_t entry = w.wlist[e];
       const uint32_t owner = entry >> 16, pos = entry & 0xffffu;
-      const float4 ra = w.rays[2 * owner], rb = w.rays[2 * owner + 1];
+      const float4 ra = w.rays[3 * owner], rb = w.rays[3 * owner + 1];
+      const double inv_a = *reinterpret_cast<const double *>(&w.rays[3 * owner + 2]);
       const float4 ex = sc.exact[pos];
       float t;
-      if (exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, ex.x, ex.y, ex.z, ex.w, rb.w, kFltMax, t)) {
+      if (exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, inv_a, ex.x, ex.y, ex.z, ex.w, rb.w, kFltMax, t)) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | sc.orig[pos];
         atomicMin(&w.best[owner], key);
       }
@@ -186,7 +201,7 @@ __device__ __forceinline__ FilterRayP pack_ray(const FilterRay &f) {
 #define RT_BCAST_HI_S0 "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
 __device__ __forceinline__ f32x2 filter_pair(const FilterRayP &f, f32x2 cx, f32x2 cy, f32x2 cz, f32x2 kp) {
   f32x2 d, t;
-  asm("v_pk_fma_f32 %0, %2, %8, %2 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"   // b  = -Bz*cz + A.B
+  RT_ASM("v_pk_fma_f32 %0, %2, %8, %2 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"   // b  = -Bz*cz + A.B
       "v_pk_fma_f32 %1, %4, %8, %9 " RT_BCAST_LO_S0 "\n\t"                 // c0 = -2Az*cz + K'
       "v_pk_fma_f32 %0, %3, %7, %0 " RT_BCAST_HI_S0 "\n\t"                 // b += -By*cy
       "v_pk_fma_f32 %1, %5, %7, %1 " RT_BCAST_HI_S0 "\n\t"                 // c0 += -2Ay*cy
@@ -209,7 +224,7 @@ __device__ __forceinline__ void filter_four_pairs(const FilterRayP &f, const flo
   const f32x2 cx1 = {q[2].x, q[2].y}, cy1 = {q[2].z, q[2].w}, cz1 = {q[3].x, q[3].y}, kp1 = {q[3].z, q[3].w};
   const f32x2 cx2 = {q[4].x, q[4].y}, cy2 = {q[4].z, q[4].w}, cz2 = {q[5].x, q[5].y}, kp2 = {q[5].z, q[5].w};
   const f32x2 cx3 = {q[6].x, q[6].y}, cy3 = {q[6].z, q[6].w}, cz3 = {q[7].x, q[7].y}, kp3 = {q[7].z, q[7].w};
-  asm("v_pk_fma_f32 %0, %8, %15, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+  RT_ASM("v_pk_fma_f32 %0, %8, %15, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
       "v_pk_fma_f32 %1, %8, %19, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
       "v_pk_fma_f32 %2, %8, %23, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
       "v_pk_fma_f32 %3, %8, %27, %8 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
@@ -265,6 +280,13 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
                                              WaveScan &w) {
   f32x2 d[kChunk / 2];
   filter_four_pairs(fr, r.q, d);
+#if RT_EXP == 12
+  {
+    f32x2 d2[kChunk / 2];
+    filter_four_pairs(fr, r.q, d2);
+    asm volatile("" ::"v"(d2[0]), "v"(d2[1]), "v"(d2[2]), "v"(d2[3]));
+  }
+#endif
   // Eight compares into eight scalar masks, OR-ed on the scalar unit, one branch
   // for the whole chunk: no branch waits on a vector compare of its own.
   unsigned long long m[kChunk];
@@ -325,6 +347,12 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     const float4 n0 = lds_bounds[nr], n1 = lds_bounds[nr + 1];
     f32x2 bx = {b0.x, b0.y}, by = {b0.z, b0.w}, bz = {b1.x, b1.y}, bk = {b1.z, b1.w};
     const f32x2 db = filter_pair(frb, bx, by, bz, bk);
+#if RT_EXP == 13
+    {
+      const f32x2 db2 = filter_pair(frb, bx, by, bz, bk);
+      asm volatile("" ::"v"(db2));
+    }
+#endif
     const unsigned long long m0 = __ballot(db[0] > 0.0f) | far_mask, m1 = __ballot(db[1] > 0.0f) | far_mask;
     const uint32_t real = sc.round_real[(base + i0) >> 4];
     tests += 2u;
@@ -372,14 +400,15 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   const uint32_t wave_first = tid & ~63u;
   WaveScan w;
   w.wlist = lds.wlist + (tid >> 6) * kWaveListCap;
-  w.rays = lds.rays + 2 * wave_first;
+  w.rays = lds.rays + 3 * wave_first;
   w.best = lds.best + wave_first;
   w.wcnt = 0;
   w.lane = tid & 63u;
   // this lane's ray and "no hit yet" key where the other lanes of the wave can reach them; the
   // key {tmax bits, 0} can only be undercut by t < tmax
-  lds.rays[2 * tid] = make_float4(A.x, A.y, A.z, a);
-  lds.rays[2 * tid + 1] = make_float4(B.x, B.y, B.z, tmin);
+  lds.rays[3 * tid] = make_float4(A.x, A.y, A.z, a);
+  lds.rays[3 * tid + 1] = make_float4(B.x, B.y, B.z, tmin);
+  *reinterpret_cast<double *>(&lds.rays[3 * tid + 2]) = 1.0 / (double)a;   // one division per ray, none per sphere
   lds.best[tid] = (unsigned long long)__float_as_uint(tmax) << 32;
   if (kBatched) {
     for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
@@ -997,7 +1026,7 @@ DeviceScene scene_view(const rt_ctx *c) {
 
 size_t scan_lds_bytes(uint32_t entries) {
   return (size_t)entries * sizeof(float4) + (size_t)(entries / 8u) * sizeof(float4) +      // pair image, bounds
-         (size_t)2 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
+         (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
          (size_t)(kBlockThreads / 64) * kWaveListCap * sizeof(uint32_t);                    // wave lists
 }
 size_t trace_lds_bytes(uint32_t n_pad) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres); }

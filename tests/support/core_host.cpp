@@ -136,13 +136,14 @@ static int closest(const rt_sphere *s, const FilterSphere *fs, size_t n, V3 A, V
                    float &t_out, uint64_t *cand) {
   FilterRay fr = make_filter_ray(A, B);
   float a = dot(B, B);
+  const double inv_a = 1.0 / (double)a;
   float best = tmax;
   int idx = -1;
   for (size_t i = 0; i < n; i++) {
     if (filter_discriminant(fr, fs[i].cx, fs[i].cy, fs[i].cz, fs[i].kprime) > 0.0f) {
       if (cand) (*cand)++;
       float t;
-      if (exact_hit(A, B, a, s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius * s[i].radius, tmin, best, t)) {
+      if (exact_hit(A, B, a, inv_a, s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius * s[i].radius, tmin, best, t)) {
         best = t;
         idx = (int)i;
       }
@@ -229,6 +230,34 @@ void core_render(const rt_camera *cam_in, const rt_sphere *s, size_t n, uint32_t
     }
   }
   if (stats) { stats[0] = paths; stats[1] = segs; stats[2] = cands; }
+}
+
+// div_by_widened_float against the plain division: random quotients and the
+// hard ones (x placed half an ulp of the quotient away from q * da, i.e. as
+// close to a rounding boundary as a double x can be).  Returns mismatches.
+uint64_t core_division_mismatches(uint64_t n, uint64_t seed) {
+  uint64_t s = seed * 0x9e3779b97f4a7c15ull + 88172645463325252ull, bad = 0;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t fb = (uint32_t)rnd();
+    if (i & 1) fb = (fb & 0xff800000u) | (0x7fffffu - (uint32_t)(rnd() & 7));   // significands of all ones
+    float a;
+    memcpy(&a, &fb, 4);
+    a = std::fabs(a);
+    if (!(a > 1e-30f && a < 1e30f)) continue;
+    const double da = a, r = 1.0 / da;
+    uint64_t xb = (rnd() & 0x800fffffffffffffull) | ((uint64_t)(1023 - 100 + (rnd() % 200)) << 52);
+    double x;
+    memcpy(&x, &xb, 8);
+    if (i % 7 == 0) {
+      const double q = x / da, qn = std::nextafter(q, INFINITY);
+      const long double mid = ((long double)q + (long double)qn) / 2;
+      x = (double)(mid * (long double)da);
+    }
+    const double want = x / da, got = div_by_widened_float(x, da, r);
+    if (memcmp(&want, &got, 8) != 0) bad++;
+  }
+  return bad;
 }
 
 }  // extern "C"

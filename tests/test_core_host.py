@@ -111,3 +111,10 @@ def test_kernel_walk_is_bit_identical_to_oracle(core, rt, oracle, scene, nx, ny,
     assert np.array_equal(lin.view(np.uint32), o["linear"].view(np.uint32))
     assert np.array_equal(fh, o["first_hit"]) and np.array_equal(hs, o["hit_sum"])
     assert st[0] == nx * ny * spp and st[1] <= o["stats"]["segments"]   # absorbed paths end early here
+
+
+def test_reciprocal_division_is_correctly_rounded(core):
+    """The drain divides by a per-ray reciprocal (three operations) where c/main.c:220, 231 divide;
+    the double quotient must be the same for every operand, the near-boundary ones included."""
+    core.core_division_mismatches.restype = C.c_uint64
+    assert core.core_division_mismatches(C.c_uint64(20_000_000), C.c_uint64(7)) == 0
