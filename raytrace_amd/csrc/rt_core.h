@@ -240,6 +240,76 @@ RT_HD f32x2 filter_discriminant2(const FilterRay2 &f, f32x2 cx, f32x2 cy, f32x2 
 
 // ------------------------------------------------------------ exact hit test
 
+// ----------------------------------------------------------- group box test
+//
+// Spheres are scanned in groups (rt_cluster.h); a ray skips a group when it
+// misses the group's axis-aligned box, tested on the half line t >= 0 with the
+// slab method in centre / half-extent form:
+//   m_k = (c_k - A_k) / B_k,  near_k = m_k - h_k / |B_k|,  far_k = m_k + h_k / |B_k|
+//   pass  <=>  min_k far_k >= max(max_k near_k, 0)
+// The test only has to be conservative: a sphere the reference reports as hit
+// (c/main.c:214-236 with t > tmin >= 0) must lie in a group that passes.
+//  * If the reference's discriminant is positive the true line passes within
+//    rho_i of the centre (rt_cluster.h), at parameter t* = -b/a.  If it also
+//    reports a root t > 0 then either its computed b is negative, so the true
+//    t* is above -4u |A-C| / |B| and the origin is within 2^-22 (|A|+|C|) of a
+//    point of that ball; or b >= 0 and the larger root is positive, which
+//    needs sqrt(D) > b, i.e. a*c <= 2u b^2, i.e. |A-C| <= r (1 + 8u): the origin
+//    is inside the ball.  Either way the half line t >= 0 meets the ball of
+//    radius rho_i + 2^-21 (|A| + |C_i| + r_i), which the box contains.
+//  * The float evaluation below (one-ulp reciprocal, three roundings per slab)
+//    is off by less than 0.75 * 2^-21 (h_k + |c_k| + |A_k|) / |B_k| per bound;
+//    the boxes are widened by more than that (rt_cluster.h), so the computed
+//    interval of every axis contains the true one.
+// Rays outside the range the margins were derived for -- |A|^2 >= 1023, a
+// direction component below 2^-30 in magnitude (its reciprocal would leave the
+// range), |B|^2 >= 2^40 -- are not culled at all (box_ray_in_range).
+
+struct GroupBox {  // centre and half extents; h = +1e30: always scanned, h = -1e30: never (padding)
+  float cx, cy, cz, hx, hy, hz;
+};
+
+struct BoxRay {
+  float ix, iy, iz;  // 1 / B_k (within one ulp)
+  float nx, ny, nz;  // -A_k * (1 / B_k)
+  float ax, ay, az;  // |1 / B_k|
+};
+
+constexpr float kBoxOriginLimit2 = 1023.0f;                // |A|^2 below this (|A| < 32)
+constexpr float kBoxMinDir = 9.313225746154785e-10f;       // 2^-30
+constexpr float kBoxMaxDir2 = 1099511627776.0f;            // 2^40
+
+RT_HD bool box_ray_in_range(V3 A, V3 B) {
+  float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(B.x), __builtin_fabsf(B.y)), __builtin_fabsf(B.z));
+  return dot(A, A) < kBoxOriginLimit2 && lo >= kBoxMinDir && dot(B, B) < kBoxMaxDir2;
+}
+
+RT_HD float rt_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+
+RT_HD BoxRay make_box_ray(V3 A, V3 B) {
+  BoxRay r;
+  r.ix = rt_rcp(B.x); r.iy = rt_rcp(B.y); r.iz = rt_rcp(B.z);
+  r.nx = -A.x * r.ix; r.ny = -A.y * r.iy; r.nz = -A.z * r.iz;
+  r.ax = __builtin_fabsf(r.ix); r.ay = __builtin_fabsf(r.iy); r.az = __builtin_fabsf(r.iz);
+  return r;
+}
+
+// nine fused multiply-adds, two three-way min/max, one max, one compare
+RT_HD bool box_pass(const BoxRay &r, const GroupBox &b) {
+  float mx = rt_fma(r.ix, b.cx, r.nx), my = rt_fma(r.iy, b.cy, r.ny), mz = rt_fma(r.iz, b.cz, r.nz);
+  float nx = rt_fma(-r.ax, b.hx, mx), ny = rt_fma(-r.ay, b.hy, my), nz = rt_fma(-r.az, b.hz, mz);
+  float fx = rt_fma(r.ax, b.hx, mx), fy = rt_fma(r.ay, b.hy, my), fz = rt_fma(r.az, b.hz, mz);
+  float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+  float tf = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+  return tf >= __builtin_fmaxf(tn, 0.0f);
+}
+
 // x / da, correctly rounded, for a divisor that is a float widened to double,
 // given r = 1.0 / da (correctly rounded).  q0 = RN(x r) is within 2^-52 of the
 // quotient; its residual e0 = x - q0 da is exact in double because da has only

@@ -54,13 +54,11 @@ constexpr int kDrainEvery = 16;       // spheres per round of the scan (two grou
 constexpr uint32_t kMaxLdsSpheres = 2048;  // 32 KiB of filter entries per staged batch
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
 constexpr int kNumCounters = 13;
-// squared origin distance up to which the group bounds are valid (rt_cluster.h), with a little room
-__device__ __forceinline__ constexpr float rtcluster_limit2() { return 1023.0f; }
 
 // The scan's arrays are in SCAN order (rt_cluster.h): position -> sphere, pads included.
 struct DeviceScene {
   const float4 *filter;   // n_pad entries, sphere pairs {cx0,cx1,cy0,cy1},{cz0,cz1,K'0,K'1}; pads never pass
-  const float4 *bounds;   // n_pad/8 entries, group-bound pairs in the same pair layout
+  const float4 *boxes;    // 3 entries per round of two groups: {cx0,cx1,cy0,cy1},{cz0,cz1,hx0,hx1},{hy0,hy1,hz0,hz1}
   const float4 *exact;    // n_pad entries {cx, cy, cz, r*r}
   const uint32_t *orig;   // n_pad entries: index in the caller's list (ties go to the lowest), ~0 for pads
   // for shading, in the CALLER's order (n entries):
@@ -69,7 +67,6 @@ struct DeviceScene {
   const int32_t *type_o;  // material type
   const uint16_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (lo byte, hi byte)
   uint32_t n, n_pad;
-  float bscale[3];        // axis factors (powers of two) of the space the group bounds live in
 };
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
@@ -102,7 +99,7 @@ __device__ __forceinline__ FilterRay dead_ray() {
 }
 
 // LDS carve-up shared by every kernel that scans.  Per workgroup: the pair
-// image of the resident batch and its group bounds; per lane: its ray (so that
+// image of the resident batch and its group boxes; per lane: its ray (so that
 // any lane of the wave can evaluate a sphere for it) and its best hit as one
 // 64-bit key {t bits, sphere index}; per wave: the list of (lane, sphere)
 // pairs that passed the filter and await exact evaluation.
@@ -111,7 +108,7 @@ constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a chunk ad
 
 struct ScanLds {
   float4 *pairs;
-  float4 *bounds;
+  float4 *boxes;                 // 3 per round (16 spheres)
   float4 *rays;                  // 3 per lane: {A, a}, {B, tmin}, {1/a as a double, -, -}
   unsigned long long *best;      // 1 per lane
   uint32_t *wlist;               // kWaveListCap per wave: (owner lane << 16) | scan position
@@ -120,8 +117,8 @@ struct ScanLds {
 __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entries) {
   ScanLds l;
   l.pairs = reinterpret_cast<float4 *>(smem);
-  l.bounds = l.pairs + entries;
-  l.rays = l.bounds + entries / 8u;
+  l.boxes = l.pairs + entries;
+  l.rays = l.boxes + 3u * (entries / 16u);
   l.best = reinterpret_cast<unsigned long long *>(l.rays + 3 * kBlockThreads);
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
   return l;
@@ -130,7 +127,7 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
 __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
                                             uint32_t tid) {
   for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[i] = sc.filter[base + i];
-  for (uint32_t i = tid; i < count / 8u; i += kBlockThreads) lds.bounds[i] = sc.bounds[base / 8u + i];
+  for (uint32_t i = tid; i < 3u * (count / 16u); i += kBlockThreads) lds.boxes[i] = sc.boxes[3u * (base / 16u) + i];
 }
 
 // What a wave carries through one scan.
@@ -264,6 +261,55 @@ __device__ __forceinline__ void filter_four_pairs(const FilterRayP &f, const flo
         "v"(cx3), "v"(cy3), "v"(cz3), "v"(kp3));                           // %25 .. %28
 }
 
+// The per-ray values of the group box test (rtcore::BoxRay) packed like
+// FilterRayP, and box_pass for the two boxes of a round at once: the nine
+// fused multiply-adds of rtcore::box_pass on both boxes (same operands, same
+// order, hence the same bits), then per box min3 / max3 / max.
+struct BoxRayP {
+  f32x2 p0;  // {1/Bx, 1/By}
+  f32x2 p1;  // {1/Bz, -Ax/Bx}
+  f32x2 p2;  // {-Ay/By, -Az/Bz}
+  f32x2 p3;  // {|1/Bx|, |1/By|}
+  f32x2 p4;  // {|1/Bz|, unused}
+};
+
+__device__ __forceinline__ BoxRayP pack_box_ray(const BoxRay &r) {
+  BoxRayP b;
+  b.p0 = f32x2{r.ix, r.iy};
+  b.p1 = f32x2{r.iz, r.nx};
+  b.p2 = f32x2{r.ny, r.nz};
+  b.p3 = f32x2{r.ax, r.ay};
+  b.p4 = f32x2{r.az, 0.0f};
+  return b;
+}
+
+// pass[i] = box i of the round is met by the lane's half line; q = the round's three LDS entries
+__device__ __forceinline__ void box_pair(const BoxRayP &r, const float4 (&q)[3], bool (&pass)[2]) {
+  const f32x2 cx = {q[0].x, q[0].y}, cy = {q[0].z, q[0].w}, cz = {q[1].x, q[1].y};
+  const f32x2 hx = {q[1].z, q[1].w}, hy = {q[2].x, q[2].y}, hz = {q[2].z, q[2].w};
+  f32x2 nx, ny, nz, fx, fy, fz, mx, my, mz;
+  RT_ASM("v_pk_fma_f32 %6, %9, %14, %10 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"   // mx = cx/Bx - Ax/Bx
+         "v_pk_fma_f32 %7, %9, %15, %11 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"   // my
+         "v_pk_fma_f32 %8, %10, %16, %11 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"  // mz
+         "v_pk_fma_f32 %0, %12, %17, %6 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"  // near x
+         "v_pk_fma_f32 %3, %12, %17, %6 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                               // far x
+         "v_pk_fma_f32 %1, %12, %18, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"  // near y
+         "v_pk_fma_f32 %4, %12, %18, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                               // far y
+         "v_pk_fma_f32 %2, %13, %19, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"  // near z
+         "v_pk_fma_f32 %5, %13, %19, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1]"                                    // far z
+         : "=&v"(nx), "=&v"(ny), "=&v"(nz), "=&v"(fx), "=&v"(fy), "=&v"(fz), "=&v"(mx), "=&v"(my), "=&v"(mz)
+         : "v"(r.p0), "v"(r.p1), "v"(r.p2), "v"(r.p3), "v"(r.p4),          // %9 .. %13
+           "v"(cx), "v"(cy), "v"(cz), "v"(hx), "v"(hy), "v"(hz));          // %14 .. %19
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float tn, tf, lim;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx[i]), "v"(ny[i]), "v"(nz[i]));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx[i]), "v"(fy[i]), "v"(fz[i]));
+    asm("v_max_f32 %0, 0, %1" : "=v"(lim) : "v"(tn));
+    pass[i] = tf >= lim;
+  }
+}
+
 // One group of kChunk spheres = kChunk float4 of the pair image (see scan_batch).
 struct ChunkRegs {
   float4 q[kChunk];
@@ -317,14 +363,14 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
 // arithmetic in a second register set, so their latency is covered by the 32
 // packed FMAs of the chunk in hand rather than waited for.
 //
-// kCull = true: each round first filters the bounding spheres of its two groups
-// (one packed evaluation, read one round ahead) and skips a group no lane's ray
-// can touch.  `far` lanes (origin outside the radius the bounds were built
-// for) take every group.
+// kCull = true: each round first tests the boxes of its two groups (one packed
+// evaluation, read one round ahead) and skips a group no lane's ray can touch.
+// `uncullable` lanes (rays outside the range the boxes are valid for) take
+// every group; lanes without a ray take none.
 template <bool kCull>
-__device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, const float4 *lds_bounds,
-                                           uint32_t base, uint32_t count, const FilterRayP &fr, const FilterRayP &frb,
-                                           bool far, WaveScan &w, HitState &h) {
+__device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, const float4 *lds_boxes,
+                                           uint32_t base, uint32_t count, const FilterRayP &fr, const BoxRayP &br,
+                                           bool alive, bool uncullable, WaveScan &w, HitState &h) {
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
   if (!kCull) {
     ChunkRegs ra, rb;
@@ -339,24 +385,25 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     }
     return;
   }
-  const unsigned long long far_mask = __ballot(far);
-  float4 b0 = lds_bounds[0], b1 = lds_bounds[1];
+  const unsigned long long all_mask = __ballot(uncullable), live_mask = __ballot(alive);
+  float4 q[3] = {lds_boxes[0], lds_boxes[1], lds_boxes[2]};
   uint32_t tests = 0;
   for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
-    const uint32_t nr = (i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u) >> 3;   // next round's bounds
-    const float4 n0 = lds_bounds[nr], n1 = lds_bounds[nr + 1];
-    f32x2 bx = {b0.x, b0.y}, by = {b0.z, b0.w}, bz = {b1.x, b1.y}, bk = {b1.z, b1.w};
-    const f32x2 db = filter_pair(frb, bx, by, bz, bk);
+    const uint32_t nr = 3u * ((i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u) >> 4);   // next round's boxes
+    const float4 n0 = lds_boxes[nr], n1 = lds_boxes[nr + 1], n2 = lds_boxes[nr + 2];
+    bool pass[2];
+    box_pair(br, q, pass);
 #if RT_EXP == 13
     {
-      const f32x2 db2 = filter_pair(frb, bx, by, bz, bk);
-      asm volatile("" ::"v"(db2));
+      bool pass2[2];
+      box_pair(br, q, pass2);
+      asm volatile("" ::"s"(__ballot(pass2[0])), "s"(__ballot(pass2[1])));
     }
 #endif
-    const unsigned long long m0 = __ballot(db[0] > 0.0f) | far_mask, m1 = __ballot(db[1] > 0.0f) | far_mask;
+    const unsigned long long m0 = (__ballot(pass[0]) & live_mask) | all_mask, m1 = (__ballot(pass[1]) & live_mask) | all_mask;
     const uint32_t real = sc.round_real[(base + i0) >> 4];
     tests += 2u;
-    h.own_groups += (db[0] > 0.0f ? 1u : 0u) + (db[1] > 0.0f ? 1u : 0u);
+    h.own_groups += (pass[0] ? 1u : 0u) + (pass[1] ? 1u : 0u);
     h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
     if (m0 != 0ull) {
       asm volatile("");
@@ -372,8 +419,9 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
       filter_chunk(r, base + i0 + kChunk, fr, w);
       tests += real >> 8;
     }
-    b0 = n0;
-    b1 = n1;
+    q[0] = n0;
+    q[1] = n1;
+    q[2] = n2;
     if (w.wcnt > kWaveListFlush - 64u * kChunk) drain_wave(sc, w, h);
   }
   h.tests += tests;
@@ -388,15 +436,10 @@ template <bool kBatched, bool kCull, bool kProfile = false>
 __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const ScanLds &lds, uint32_t tid, bool alive,
                                                   V3 A, V3 B, float tmin, float tmax, HitState &h) {
   const FilterRayP fr = pack_ray(alive ? make_filter_ray(A, B) : dead_ray());
-  // the same ray in the scaled space of the group bounds (power-of-two factors: exact products)
-  FilterRayP frb = fr;
-  if (kCull) {
-    const V3 sc3 = v3(sc.bscale[0], sc.bscale[1], sc.bscale[2]);
-    frb = pack_ray(alive ? make_filter_ray(sc3 * A, sc3 * B) : dead_ray());
-  }
+  const BoxRayP br = pack_box_ray(make_box_ray(A, B));
   const float a = dot(B, B);
-  // origins beyond the radius the group bounds were derived for scan every group
-  const bool far = alive && !(dot(A, A) < (float)(rtcluster_limit2()));
+  // rays outside the range the group boxes were derived for scan every group
+  const bool uncullable = kCull && alive && !box_ray_in_range(A, B);
   const uint32_t wave_first = tid & ~63u;
   WaveScan w;
   w.wlist = lds.wlist + (tid >> 6) * kWaveListCap;
@@ -416,10 +459,10 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       __syncthreads();
       stage_batch(sc, lds, base, count, tid);
       __syncthreads();
-      scan_batch<kCull>(sc, lds.pairs, lds.bounds, base, count, fr, frb, far, w, h);
+      scan_batch<kCull>(sc, lds.pairs, lds.boxes, base, count, fr, br, alive, uncullable, w, h);
     }
   } else {
-    scan_batch<kCull>(sc, lds.pairs, lds.bounds, 0u, sc.n_pad, fr, frb, far, w, h);
+    scan_batch<kCull>(sc, lds.pairs, lds.boxes, 0u, sc.n_pad, fr, br, alive, uncullable, w, h);
   }
   if (!kCull) h.tests += sc.n;
   const unsigned long long d0 = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -980,12 +1023,11 @@ struct rt_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events[kHistory];
   int trace_used[kHistory] = {};
   long renders = 0;
-  DevBuf<float4> filter, bounds, exact, geom_o, mat_o;
+  DevBuf<float4> filter, boxes, exact, geom_o, mat_o;
   DevBuf<int32_t> type_o;
   DevBuf<uint32_t> orig;
   DevBuf<uint16_t> round_real;
   uint32_t n = 0, n_pad = 0;
-  float bscale[3] = {1.0f, 1.0f, 1.0f};
   DevBuf<unsigned long long> counters;
   DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
   DevBuf<float4> rad;                // per-path radiance of one sample batch
@@ -1020,12 +1062,11 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->bounds.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->round_real.p, c->n, c->n_pad,
-                     {c->bscale[0], c->bscale[1], c->bscale[2]}};
+  return DeviceScene{c->filter.p, c->boxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->round_real.p, c->n, c->n_pad};
 }
 
 size_t scan_lds_bytes(uint32_t entries) {
-  return (size_t)entries * sizeof(float4) + (size_t)(entries / 8u) * sizeof(float4) +      // pair image, bounds
+  return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u) * sizeof(float4) +  // pair image, boxes
          (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
          (size_t)(kBlockThreads / 64) * kWaveListCap * sizeof(uint32_t);                    // wave lists
 }
@@ -1236,7 +1277,7 @@ int rt_ctx_destroy(rt_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->filter.release();
-  c->bounds.release();
+  c->boxes.release();
   c->orig.release();
   c->round_real.release();
   c->exact.release();
@@ -1300,7 +1341,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   const uint32_t n_pad = L.n_scan;
   static_assert(rtcluster::kGroup == kChunk, "one group per chunk");
   if (n_pad > kMaxSpheres) return fail(RT_ERR_LIMIT, "too many spheres after padding");
-  std::vector<float4> filter(n_pad), exact(n_pad), bounds(n_pad / 8), geom_o(n), mat_o(n);
+  std::vector<float4> filter(n_pad), exact(n_pad), boxes(3 * (n_pad / 16)), geom_o(n), mat_o(n);
   std::vector<int32_t> type_o(n);
   std::vector<uint16_t> round_real(n_pad / 16);
   std::vector<FilterSphere> fs(n_pad);
@@ -1327,19 +1368,20 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     filter[p2 + 1] = make_float4(fs[p2].cz, fs[p2 + 1].cz, fs[p2].kprime, fs[p2 + 1].kprime);
   }
   for (uint32_t g = 0; g < n_pad / 8; g += 2) {
-    const FilterSphere &b0 = L.bounds[g], &b1 = L.bounds[g + 1];
-    bounds[g] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
-    bounds[g + 1] = make_float4(b0.cz, b1.cz, b0.kprime, b1.kprime);
+    const GroupBox &b0 = L.boxes[g], &b1 = L.boxes[g + 1];
+    boxes[3 * (g / 2)] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
+    boxes[3 * (g / 2) + 1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
+    boxes[3 * (g / 2) + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
     round_real[g / 2] = (uint16_t)(L.real_in_group[g] | (L.real_in_group[g + 1] << 8));
   }
   int rc;
-  if ((rc = c->filter.reserve(n_pad)) || (rc = c->bounds.reserve(n_pad / 8)) || (rc = c->exact.reserve(n_pad)) ||
+  if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->exact.reserve(n_pad)) ||
       (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
       (rc = c->orig.reserve(n_pad)) || (rc = c->round_real.reserve(n_pad / 16)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->bounds.p, bounds.data(), (n_pad / 8) * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->boxes.p, boxes.data(), 3 * (n_pad / 16) * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->exact.p, exact.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->geom_o.p, geom_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
@@ -1348,7 +1390,6 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint16_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
   c->n_pad = n_pad;
-  for (int d = 0; d < 3; ++d) c->bscale[d] = L.scale[d];
   return RT_OK;
 }
 

@@ -49,7 +49,7 @@ def rt():
 
 
 def build_core_host():
-    deps = [CORE_SRC, os.path.join(ROOT, "raytrace_amd", "csrc", "rt_core.h")]
+    deps = [CORE_SRC] + [os.path.join(ROOT, "raytrace_amd", "csrc", h) for h in ("rt_core.h", "rt_cluster.h")]
     if not os.path.exists(CORE_SO) or any(os.path.getmtime(d) > os.path.getmtime(CORE_SO) for d in deps):
         os.makedirs(os.path.dirname(CORE_SO), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",

@@ -78,35 +78,33 @@ uint64_t core_filter_pair_mismatches(const rt_sphere *s, size_t n, const float *
   return bad;
 }
 
-// Group culling (rt_cluster.h): for every ray whose origin is inside the limit
-// and every group whose bound the ray's filter rejects, no member may pass its
-// own filter.  Returns the number of violations (must be 0); *culled /
-// *groups = how much a single ray skips.
+// Group culling (rt_cluster.h): for every ray the kernel would cull with and
+// every group whose box the ray's half line misses, the reference's hit test
+// (c/main.c:214-236, any tmin >= 0) must report no hit for any member.
+// Returns the number of violations (must be 0); *culled / *groups = how much
+// a single ray skips.
 uint64_t core_cull_check(const rt_sphere *s, size_t n, const float *rays, size_t n_rays, uint64_t *culled,
                          uint64_t *groups) {
   const rtcluster::Layout L = rtcluster::build_layout(s, n);
-  std::vector<FilterSphere> fs(L.n_scan);
-  for (uint32_t p = 0; p < L.n_scan; p++) {
-    uint32_t i = L.order[p];
-    fs[p] = i == 0xffffffffu ? FilterSphere{0.0f, 0.0f, 0.0f, 1.0e30f}
-                             : make_filter_sphere(s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius);
-  }
   uint64_t bad = 0, cul = 0, tot = 0;
   for (size_t r = 0; r < n_rays; r++) {
     V3 A = v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]);
     V3 B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
-    if (!(dot(A, A) < 1023.0f)) continue;   // the kernel scans every group for such rays
-    FilterRay fr = make_filter_ray(A, B);
-    const V3 sc3 = v3(L.scale[0], L.scale[1], L.scale[2]);
-    FilterRay frb = make_filter_ray(sc3 * A, sc3 * B);   // the bounds live in the axis-scaled space
-    for (size_t g = 0; g < L.bounds.size(); g++) {
-      const FilterSphere &b = L.bounds[g];
+    if (!box_ray_in_range(A, B)) continue;   // the kernel scans every group for such rays
+    const BoxRay br = make_box_ray(A, B);
+    const float a = dot(B, B);
+    const double inv_a = 1.0 / (double)a;
+    for (size_t g = 0; g < L.boxes.size(); g++) {
       tot++;
-      if (filter_discriminant(frb, b.cx, b.cy, b.cz, b.kprime) > 0.0f) continue;
+      if (box_pass(br, L.boxes[g])) continue;
       cul++;
       for (int k = 0; k < rtcluster::kGroup; k++) {
-        const FilterSphere &m = fs[g * rtcluster::kGroup + k];
-        if (filter_discriminant(fr, m.cx, m.cy, m.cz, m.kprime) > 0.0f) bad++;
+        const uint32_t i = L.order[g * rtcluster::kGroup + k];
+        if (i == 0xffffffffu) continue;
+        float t;
+        if (exact_hit(A, B, a, inv_a, s[i].center[0], s[i].center[1], s[i].center[2], s[i].radius * s[i].radius, 0.0f,
+                      kFltMax, t))
+          bad++;
       }
     }
   }
@@ -126,9 +124,9 @@ int core_layout_check(const rt_sphere *s, size_t n, uint32_t *n_scan, uint32_t *
     }
   for (size_t i = 0; i < n; i++)
     if (seen[i] != 1) return 2;
-  if (L.n_scan % 16 || L.bounds.size() * 8 != L.n_scan || L.real_in_group.size() != L.bounds.size()) return 3;
+  if (L.n_scan % 16 || L.boxes.size() * 8 != L.n_scan || L.real_in_group.size() != L.boxes.size()) return 3;
   *n_scan = L.n_scan;
-  *n_groups = (uint32_t)L.bounds.size();
+  *n_groups = (uint32_t)L.boxes.size();
   return 0;
 }
 

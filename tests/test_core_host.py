@@ -42,6 +42,26 @@ def adversarial_rays(rng, spheres, n):
     return np.concatenate([A, B], axis=1).astype(np.float32)
 
 
+def leaving_rays(rng, spheres, n):
+    """Rays that start on, just inside or just outside a sphere and head away from it, along it or barely
+    towards it, with directions from 1e-6 to 1e3 long and some components exactly zero: the cases in which
+    'the group is behind the ray' is a close call."""
+    idx = rng.integers(0, len(spheres), n)
+    c, r = spheres["center"][idx].astype(np.float64), spheres["radius"][idx].astype(np.float64)
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    off = rng.choice([0, 1e-7, -1e-7, 1e-6, -1e-6, 1e-4, -1e-4, 1e-2], n)
+    A = c + nrm * (r * (1 + off))[:, None]
+    tang = np.cross(nrm, rng.normal(size=(n, 3)))
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True)
+    lean = rng.choice([0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3, 0.3, -0.3, 1.0], n)   # > 0 leaves the sphere
+    B = tang * rng.uniform(0, 1, n)[:, None] + nrm * lean[:, None]
+    B *= rng.choice([1e-6, 1e-4, 1e-2, 1, 1, 1e3], n)[:, None]
+    B[rng.random(n) < 0.05, rng.integers(0, 3)] = 0.0
+    keep = np.linalg.norm(A, axis=1) < 31.0
+    return np.concatenate([A, B], axis=1).astype(np.float32)[keep]
+
+
 @pytest.mark.parametrize("builder", ["small_scene", "random_scene", "dense"])
 def test_filter_has_no_false_negatives(core, rt, builder):
     sc = rt.random_scene(100)[::9][:3000] if builder == "dense" else getattr(rt, builder)()
@@ -56,13 +76,13 @@ def test_filter_has_no_false_negatives(core, rt, builder):
 
 
 @pytest.mark.parametrize("builder", ["small_scene", "random_scene", "glass_scene", "dense"])
-def test_group_culling_never_hides_a_candidate(core, rt, builder):
+def test_group_culling_never_hides_a_hit(core, rt, builder):
     sc = rt.random_scene(100)[::7][:4000] if builder == "dense" else getattr(rt, builder)()
     n_scan, n_groups = C.c_uint32(), C.c_uint32()
     assert core.core_layout_check(vp(sc), C.c_size_t(len(sc)), C.byref(n_scan), C.byref(n_groups)) == 0
     assert n_scan.value >= len(sc) and n_scan.value < len(sc) + 64 + len(sc) // 4
     rng = np.random.default_rng(8)
-    rays = np.concatenate([random_rays(rng, 4000, sc), adversarial_rays(rng, sc, 8000)])
+    rays = np.concatenate([random_rays(rng, 20000, sc), adversarial_rays(rng, sc, 20000), leaving_rays(rng, sc, 60000)])
     rays[::5, :3] *= 2.5          # some origins beyond the culling limit too
     culled, groups = C.c_uint64(), C.c_uint64()
     core.core_cull_check.restype = C.c_uint64
