@@ -31,6 +31,7 @@ for flags, label in ap_flags:
     if flags & 1:
         tot = c["cycles_total"]
         out.update(frac_scan=c["cycles_scan"] / tot, frac_drain=c["cycles_drain"] / tot, frac_shade=c["cycles_shade"] / tot,
+                   frac_refill_and_loop=1.0 - (c["cycles_scan"] + c["cycles_drain"] + c["cycles_shade"]) / tot,
                    shader_clock_ghz=c['cycles_total'] / max(1, c['realtime_total']) * 0.1,
                    own_groups_per_segment=c['own_groups'] / c['segments'], wave_groups_per_segment=c['wave_groups'] / c['segments'],
                    lane_occupancy=c["live_lane_iterations"] / (64.0 * c["wave_iterations"]),

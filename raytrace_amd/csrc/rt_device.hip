@@ -71,6 +71,14 @@ struct DeviceScene {
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
+// shader clock for the profiling builds, read once everything issued before it has completed
+__device__ __forceinline__ unsigned long long tick() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  asm volatile("" ::: "memory");
+  return t;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -104,7 +112,7 @@ __device__ __forceinline__ FilterRay dead_ray() {
 // 64-bit key {t bits, sphere index}; per wave: the list of (lane, sphere)
 // pairs that passed the filter and await exact evaluation.
 constexpr uint32_t kWaveListCap = 1024;             // entries per wave
-constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a chunk adds at most 64*kChunk
+constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a chunk adds at most 64*kChunk: drain above this
 
 struct ScanLds {
   float4 *pairs;
@@ -131,12 +139,15 @@ __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds
 }
 
 // What a wave carries through one scan.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
 struct WaveScan {
-  uint32_t *wlist;               // this wave's list
+  uint32_t wlist_off;            // LDS byte address of this wave's list (wave-uniform, held in a scalar register)
   const float4 *rays;            // this wave's 64 rays (lane l at [3l] .. [3l+2])
   unsigned long long *best;      // this wave's 64 keys
   uint32_t wcnt;                 // entries in the list (wave-uniform)
   uint32_t lane;
+  uint32_t lane16;               // lane << 16, the owner field of a list entry
 };
 
 // Exact evaluation (c/main.c:214-236) of the listed (lane, sphere) pairs, 64
@@ -153,7 +164,7 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
   for (uint32_t e0 = 0; e0 < w.wcnt; e0 += 64u) {
     const uint32_t e = e0 + w.lane;
     if (e < w.wcnt) {
-      const uint32_t entry = w.wlist[e];
+      const uint32_t entry = *(lds_u32 *)(uintptr_t)(w.wlist_off + (e << 2));
       const uint32_t owner = entry >> 16, pos = entry & 0xffffu;
       const float4 ra = w.rays[3 * owner], rb = w.rays[3 * owner + 1];
       const double inv_a = *reinterpret_cast<const double *>(&w.rays[3 * owner + 2]);
@@ -345,9 +356,14 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
     for (int u = 0; u < kChunk; ++u) {
       if (m[u] != 0ull) {
         asm volatile("");
+        // address = scalar (list base + 4 * count so far) + 4 * (passing lanes below this one),
+        // value = lane field | scalar position: four vector operations per listed sphere
         const uint32_t rank =
             __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
-        if (d[u >> 1][u & 1] > 0.0f) w.wlist[w.wcnt + rank] = (w.lane << 16) | (first_index + u);
+        uint32_t pos = first_index + u, tail = w.wlist_off + (w.wcnt << 2);
+        asm("" : "+s"(pos), "+s"(tail));   // keep each one scalar operand
+        lds_u32 *dst = (lds_u32 *)(uintptr_t)(tail + (rank << 2));
+        if (d[u >> 1][u & 1] > 0.0f) *dst = w.lane16 | pos;
         w.wcnt += (uint32_t)__popcll(m[u]);
       }
     }
@@ -377,11 +393,12 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     load_chunk(ra, lds_pairs, 0);
     for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
       load_chunk(rb, lds_pairs, i0 + kChunk);
+      if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);   // rare: the list usually lasts the whole scan
       filter_chunk(ra, base + i0, fr, w);
       // the read past the end of the last round stays inside the image and is never used
       load_chunk(ra, lds_pairs, i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u);
+      if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);
       filter_chunk(rb, base + i0 + kChunk, fr, w);
-      if (w.wcnt > kWaveListFlush - 64u * kChunk) drain_wave(sc, w, h);
     }
     return;
   }
@@ -407,6 +424,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
     if (m0 != 0ull) {
       asm volatile("");
+      if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);   // rare: the list usually lasts the whole scan
       ChunkRegs r;
       load_chunk(r, lds_pairs, i0);
       filter_chunk(r, base + i0, fr, w);
@@ -414,6 +432,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     }
     if (m1 != 0ull) {
       asm volatile("");
+      if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);
       ChunkRegs r;
       load_chunk(r, lds_pairs, i0 + kChunk);
       filter_chunk(r, base + i0 + kChunk, fr, w);
@@ -422,7 +441,6 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     q[0] = n0;
     q[1] = n1;
     q[2] = n2;
-    if (w.wcnt > kWaveListFlush - 64u * kChunk) drain_wave(sc, w, h);
   }
   h.tests += tests;
 }
@@ -442,11 +460,13 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   const bool uncullable = kCull && alive && !box_ray_in_range(A, B);
   const uint32_t wave_first = tid & ~63u;
   WaveScan w;
-  w.wlist = lds.wlist + (tid >> 6) * kWaveListCap;
+  w.wlist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)(uint32_t)(uintptr_t)(lds_u32 *)(lds.wlist + (tid >> 6) * kWaveListCap));
   w.rays = lds.rays + 3 * wave_first;
   w.best = lds.best + wave_first;
   w.wcnt = 0;
   w.lane = tid & 63u;
+  w.lane16 = w.lane << 16;
   // this lane's ray and "no hit yet" key where the other lanes of the wave can reach them; the
   // key {tmax bits, 0} can only be undercut by t < tmax
   lds.rays[3 * tid] = make_float4(A.x, A.y, A.z, a);
@@ -465,9 +485,9 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
     scan_batch<kCull>(sc, lds.pairs, lds.boxes, 0u, sc.n_pad, fr, br, alive, uncullable, w, h);
   }
   if (!kCull) h.tests += sc.n;
-  const unsigned long long d0 = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long d0 = kProfile ? tick() : 0ull;
   drain_wave(sc, w, h);
-  if (kProfile) h.drain_cycles = __builtin_amdgcn_s_memtime() - d0;
+  if (kProfile) h.drain_cycles = tick() - d0;
   const unsigned long long key = lds.best[tid];
   const float t = __uint_as_float((uint32_t)(key >> 32));
   if (alive && t < tmax) {
@@ -599,12 +619,12 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
     if (kProfile) {
       n_iter++;
       n_live += (unsigned long long)__popcll(__ballot(alive));
-      c0 = __builtin_amdgcn_s_memtime();
+      c0 = tick();
     }
     HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0ull};
     closest_hit_scene<kBatched, kCull, kProfile>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
     if (kProfile) {
-      c2 = __builtin_amdgcn_s_memtime();
+      c2 = tick();
       c1 = c2 - h.drain_cycles;
     }
 
@@ -655,7 +675,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
     }
     n_paths += (unsigned long long)__popcll(__ballot(finished));
     if (kProfile) {
-      unsigned long long c3 = __builtin_amdgcn_s_memtime();
+      unsigned long long c3 = tick();
       c_scan += c1 - c0;
       c_drain += c2 - c1;
       c_shade += c3 - c2;
