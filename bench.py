@@ -68,6 +68,18 @@ def cpu_baseline(nx, ny, scene_name, half_extent, max_depth):
     return res
 
 
+def hbm_traffic(kernel_key):
+    """HBM bytes per launch of the trace kernel from the last committed rocprofv3 counter passes
+    (profiles/pmc_latest.json, written by benchmarks/summarize_pmc.py): WRITE_SIZE is exact for the 16-byte
+    stores of the radiance buffer, FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 and is doubled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            d = json.load(f)[kernel_key]
+        return (d["WRITE_SIZE_KB"] + 2.0 * d["FETCH_SIZE_KB"]) * 1024.0, d.get("source")
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +90,7 @@ def main():
     ap.add_argument("--kernel", default="mega", choices=["mega", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-scan", action="store_true", help="RT_FLAG_FULL_SCAN: filter every sphere for every ray (no group culling)")
+    ap.add_argument("--no-linear-scan-leg", action="store_true", help="skip the extra (untimed for `value`) full-scan measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -157,10 +170,34 @@ def main():
     paths_per_step_rank = my_rows * nx * spp_total
     total_paths_per_step = nx * ny * spp_total
 
+    # the same frame with every sphere filtered for every ray (the reference's linear scan, nothing culled):
+    # not part of `value`, reported beside it because it is the mode the FP32 roofline argument is about
+    linear = None
+    if world == 1 and rank == 0 and args.kernel == "mega" and not args.full_scan and not args.no_linear_scan_leg:
+        ljob = FrameShards(nx, ny, spp_total, world, tile_rows, max_depth=max_depth, seed=0, kernel=kernel, flags=2).job(rank)
+        r.render_device(cam, ljob, tiles.data_ptr())
+        torch.cuda.synchronize(dev)
+        r.counters(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.render_device(cam, ljob, tiles.data_ptr())
+        torch.cuda.synchronize(dev)
+        ldt = time.perf_counter() - t0
+        lc = r.counters()
+        l_ms = float(np.mean([r.trace_ms(back) for back in range(args.steps)]))
+        l_ach = FLOP_PER_TEST * lc["tests"] / args.steps / (l_ms * 1e-3) / 1e12
+        linear = {"value": total_paths_per_step * args.steps / ldt, "unit": "camera paths/s", "ms_per_step": ldt / args.steps * 1e3,
+                  "roofline": {"bound": "fp32_valu", "achieved": l_ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": l_ach / FP32_PEAK_TFLOPS, "kernel": "trace_kernel (RT_FLAG_FULL_SCAN)",
+                               "kernel_ms_avg": l_ms, "tests_per_path": lc["tests"] / max(1, lc["paths"])}}
+
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         tests_per_launch = counters["tests"] / args.steps
         achieved = FLOP_PER_TEST * tests_per_launch / (k_ms * 1e-3) / 1e12
+        traffic, traffic_source = hbm_traffic("full" if args.full_scan else "culled") if args.kernel == "mega" else (None, None)
+        if traffic is not None:
+            traffic *= spp_total / 64.0 * my_rows / ny        # the counters were collected on the 64-spp full frame
         out = {
             "metric": "camera paths/sec (Msamples/s) final scene 1920x1080; % FP32 VALU peak",
             "value": total_paths_per_step * args.steps / dt,
@@ -180,7 +217,7 @@ def main():
                        "kernel": args.kernel, "scan": "full" if args.full_scan else "group-culled", "paths_per_step": total_paths_per_step,
                        "msamples_per_s": total_paths_per_step * args.steps / dt / 1e6},
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "trace_kernel" if args.kernel == "mega" else "wavefront stages",
                          "kernel_ms_avg": k_ms, "render_ms_avg": float(np.mean(launch_ms)),
                          "flop_per_test": FLOP_PER_TEST,
@@ -190,6 +227,11 @@ def main():
                          "exact_evaluations_per_segment": counters["candidates"] / max(1, counters["segments"]),
                          "rank0_paths_per_launch": paths_per_step_rank},
         }
+        if linear is not None:
+            out["linear_scan"] = linear
+            # what the culled kernel delivers in units of the linear scan's work
+            out["roofline"]["linear_scan_equivalent_frac"] = (FLOP_PER_TEST * linear["roofline"]["tests_per_path"] * out["value"]
+                                                              / 1e12 / FP32_PEAK_TFLOPS)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, scene_name, half_extent, max_depth)
         print(json.dumps(out), flush=True)

@@ -8,7 +8,7 @@ tag=${1:-prof}; shift || true
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-cmd=(python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@")
+cmd=(python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-linear-scan-leg "$@")
 
 run() {  # name, then rocprofv3 options
   local name=$1; shift

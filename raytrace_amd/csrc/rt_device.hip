@@ -65,7 +65,8 @@ struct DeviceScene {
   const float4 *geom_o;   // {cx, cy, cz, radius}
   const float4 *mat_o;    // {albedo rgb, param}
   const int32_t *type_o;  // material type
-  const uint16_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (lo byte, hi byte)
+  const uint32_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (byte 0, byte 1); dwords so
+                               // that the wave-uniform read is a scalar load
   uint32_t n, n_pad;
 };
 
@@ -140,6 +141,9 @@ __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds
 
 // What a wave carries through one scan.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// read-only for the whole launch and read at wave-uniform addresses: through the constant address space the
+// compiler turns such reads into scalar loads
+typedef const __attribute__((address_space(4))) uint32_t const_u32;
 
 struct WaveScan {
   uint32_t wlist_off;            // LDS byte address of this wave's list (wave-uniform, held in a scalar register)
@@ -403,11 +407,9 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     return;
   }
   const unsigned long long all_mask = __ballot(uncullable), live_mask = __ballot(alive);
-  float4 q[3] = {lds_boxes[0], lds_boxes[1], lds_boxes[2]};
   uint32_t tests = 0;
-  for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
-    const uint32_t nr = 3u * ((i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u) >> 4);   // next round's boxes
-    const float4 n0 = lds_boxes[nr], n1 = lds_boxes[nr + 1], n2 = lds_boxes[nr + 2];
+  // one round: the two boxes in q, then the groups some lane's ray can touch
+  auto round = [&](const float4 (&q)[3], uint32_t i0) {
     bool pass[2];
     box_pair(br, q, pass);
 #if RT_EXP == 13
@@ -418,7 +420,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     }
 #endif
     const unsigned long long m0 = (__ballot(pass[0]) & live_mask) | all_mask, m1 = (__ballot(pass[1]) & live_mask) | all_mask;
-    const uint32_t real = sc.round_real[(base + i0) >> 4];
+    const uint32_t real = ((const_u32 *)(uintptr_t)sc.round_real)[(base + i0) >> 4];
     tests += 2u;
     h.own_groups += (pass[0] ? 1u : 0u) + (pass[1] ? 1u : 0u);
     h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
@@ -438,9 +440,21 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
       filter_chunk(r, base + i0 + kChunk, fr, w);
       tests += real >> 8;
     }
-    q[0] = n0;
-    q[1] = n1;
-    q[2] = n2;
+  };
+  // Two rounds per trip with two sets of box registers, each read one round before its use, so that
+  // no register is copied; a read past the last round is redirected to round 0 and never used.
+  float4 qa[3] = {lds_boxes[0], lds_boxes[1], lds_boxes[2]}, qb[3];
+  for (uint32_t i0 = 0; i0 < count; i0 += 2 * kDrainEvery) {
+    const uint32_t ib = 3u * ((i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u) >> 4);
+    qb[0] = lds_boxes[ib];
+    qb[1] = lds_boxes[ib + 1];
+    qb[2] = lds_boxes[ib + 2];
+    round(qa, i0);
+    const uint32_t ia = 3u * ((i0 + 2 * kDrainEvery < count ? i0 + 2 * kDrainEvery : 0u) >> 4);
+    qa[0] = lds_boxes[ia];
+    qa[1] = lds_boxes[ia + 1];
+    qa[2] = lds_boxes[ia + 2];
+    if (i0 + kDrainEvery < count) round(qb, i0 + kDrainEvery);
   }
   h.tests += tests;
 }
@@ -1046,7 +1060,7 @@ struct rt_ctx {
   DevBuf<float4> filter, boxes, exact, geom_o, mat_o;
   DevBuf<int32_t> type_o;
   DevBuf<uint32_t> orig;
-  DevBuf<uint16_t> round_real;
+  DevBuf<uint32_t> round_real;
   uint32_t n = 0, n_pad = 0;
   DevBuf<unsigned long long> counters;
   DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
@@ -1363,7 +1377,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   if (n_pad > kMaxSpheres) return fail(RT_ERR_LIMIT, "too many spheres after padding");
   std::vector<float4> filter(n_pad), exact(n_pad), boxes(3 * (n_pad / 16)), geom_o(n), mat_o(n);
   std::vector<int32_t> type_o(n);
-  std::vector<uint16_t> round_real(n_pad / 16);
+  std::vector<uint32_t> round_real(n_pad / 16);
   std::vector<FilterSphere> fs(n_pad);
   for (size_t i = 0; i < n; ++i) {
     const rt_sphere &s = spheres[i];
@@ -1392,7 +1406,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     boxes[3 * (g / 2)] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
     boxes[3 * (g / 2) + 1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
     boxes[3 * (g / 2) + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
-    round_real[g / 2] = (uint16_t)(L.real_in_group[g] | (L.real_in_group[g + 1] << 8));
+    round_real[g / 2] = (uint32_t)(L.real_in_group[g] | (L.real_in_group[g + 1] << 8));
   }
   int rc;
   if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->exact.reserve(n_pad)) ||
@@ -1407,7 +1421,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->type_o.p, type_o.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint16_t), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
   c->n_pad = n_pad;
   return RT_OK;
