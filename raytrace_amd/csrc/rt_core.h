@@ -117,13 +117,17 @@ struct Camera {  // same layout as rt_camera
   float lens_radius;
 };
 
-// c/structs.c:81-92
-RT_HD void camera_ray(const Camera &c, float x, float y, Rng &g, V3 &A, V3 &B) {
-  V3 rd = c.lens_radius * unit_ball(g);
+// c/structs.c:81-92, given the point `ball` drawn by random_in_unit_ball (c/structs.c:83)
+RT_HD void camera_ray_from(const Camera &c, float x, float y, V3 ball, V3 &A, V3 &B) {
+  V3 rd = c.lens_radius * ball;
   V3 off = rd.x * c.u + rd.y * c.v;
   V3 on_plane = c.llc + (x * c.horiz + y * c.vert);
   B = (on_plane - c.origin) - off;
   A = c.origin + off;
+}
+
+RT_HD void camera_ray(const Camera &c, float x, float y, Rng &g, V3 &A, V3 &B) {
+  camera_ray_from(c, x, y, unit_ball(g), A, B);
 }
 
 // pixel -> (x, y) of c/main.c:465-466 with one band (ymin 0, ymax 1);
@@ -379,26 +383,25 @@ struct Material {
   float param;
 };
 
-// c/main.c:163-211.  p, n: hit point and normal.  Returns false for an
-// absorbed metal ray (c/main.c:179); otherwise atten and the new ray.
-RT_HD bool scatter(const Material &m, V3 A, V3 B, V3 p, V3 n, Rng &g, V3 &atten, V3 &oA, V3 &oB) {
-  (void)A;
-  oA = p;
-  if (m.type == 0) {  // matte, c/main.c:168-173
-    V3 target = (p + n) + unit_ball(g);
-    atten = m.albedo;
-    oB = target - p;
-    return true;
-  }
-  if (m.type == 1) {  // metal, c/main.c:174-180
-    V3 mirrored = reflect(normalize(B), n);
-    V3 dir = mirrored + m.param * unit_ball(g);
-    atten = m.albedo;
-    oB = dir;
-    return dot(dir, n) > 0.0f;
-  }
-  // dielectric, c/main.c:181-206
-  float idx = m.param;
+// The three materials of c/main.c:163-211, split so that a caller can draw the
+// unit-ball point of the matte and the metal case (their only use of the
+// generator, and the first thing either does) in one place.
+//
+// matte, c/main.c:168-173: the new direction
+RT_HD V3 scatter_matte(V3 p, V3 n, V3 ball) {
+  V3 target = (p + n) + ball;
+  return target - p;
+}
+
+// metal, c/main.c:174-180: the new direction; false when the ray is absorbed (c/main.c:179)
+RT_HD bool scatter_metal(V3 B, V3 n, float fuzz, V3 ball, V3 &dir) {
+  V3 mirrored = reflect(normalize(B), n);
+  dir = mirrored + fuzz * ball;
+  return dot(dir, n) > 0.0f;
+}
+
+// dielectric, c/main.c:181-206: the new direction
+RT_HD V3 scatter_dielectric(V3 B, V3 n, float idx, Rng &g) {
   float bn = dot(B, n);
   V3 outward;
   float ni_over_nt, cosine;
@@ -416,8 +419,25 @@ RT_HD bool scatter(const Material &m, V3 A, V3 B, V3 p, V3 n, Rng &g, V3 &atten,
   if (refract(B, outward, ni_over_nt, bent)) {
     go_through = next_uniform(g) >= (double)schlick(cosine, idx);
   }
-  oB = go_through ? bent : reflect(B, n);
+  return go_through ? bent : reflect(B, n);
+}
+
+// c/main.c:163-211.  p, n: hit point and normal.  Returns false for an
+// absorbed metal ray (c/main.c:179); otherwise atten and the new ray.
+RT_HD bool scatter(const Material &m, V3 A, V3 B, V3 p, V3 n, Rng &g, V3 &atten, V3 &oA, V3 &oB) {
+  (void)A;
+  oA = p;
+  if (m.type == 0) {
+    atten = m.albedo;
+    oB = scatter_matte(p, n, unit_ball(g));
+    return true;
+  }
+  if (m.type == 1) {
+    atten = m.albedo;
+    return scatter_metal(B, n, m.param, unit_ball(g), oB);
+  }
   atten = v3(1.0f, 1.0f, 1.0f);
+  oB = scatter_dielectric(B, n, m.param, g);
   return true;
 }
 

@@ -579,8 +579,75 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
   const unsigned long long c_begin = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long r_begin = kProfile ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
+  // One trip = one bounce of every live lane: (1) closest hit, (2) shading up to the point where a
+  // matte or metal hit needs its point in the unit ball, (3) new paths for the lanes whose path just
+  // ended, up to the point where the camera needs its point in the unit ball (c/structs.c:83), (4) ONE
+  // rejection loop (c/structs.c:39-47 / c/main.c:124-131) for all of those lanes together -- run
+  // separately, each of the three loops would cost the wave its slowest lane's trip count -- and
+  // (5) the rest of the scatter or of the camera ray.
+  enum : int { kNone = 0, kMatte = 1, kMetal = 2, kNewPath = 3 };
+  bool work = false;   // some lane of the wave (batched: of the workgroup) has a ray to trace
   for (;;) {
-    // ---- (0): hand new paths to idle lanes
+    unsigned long long c0 = 0, c1 = 0, c2 = 0;
+    int pending = kNone;
+    V3 p = v3(0, 0, 0), n = v3(0, 0, 0), albedo = v3(0, 0, 0);   // (kNewPath: p.x, p.y hold the pixel's x, y)
+    float fuzz = 0.0f;
+    bool finished = false;
+    if (kProfile) c0 = c1 = c2 = tick();
+    if (work) {
+      // ---- (1): closest hit
+      if (kProfile) {
+        n_iter++;
+        n_live += (unsigned long long)__popcll(__ballot(alive));
+      }
+      HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0ull};
+      closest_hit_scene<kBatched, kCull, kProfile>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
+      if (kProfile) {
+        c2 = tick();
+        c1 = c2 - h.drain_cycles;
+      }
+      {
+        const uint32_t live = (uint32_t)__popcll(__ballot(alive));
+        n_seg += live;
+        n_cand += h.cand;
+        n_tests += (unsigned long long)h.tests * live;
+      }
+      // ---- (2): shade, first part
+      if (alive) {
+        if (kProfile) {
+          n_own += h.own_groups;
+          n_wave += h.wave_groups;
+        }
+        bool done = false;
+        if (depth == 0) first_hit = h.index;
+        if (h.index >= 0) {
+          const float4 e = sc.geom_o[h.index];
+          const float4 m4 = sc.mat_o[h.index];
+          const int type = sc.type_o[h.index];
+          p = A + h.closest * B;                              // c/structs.c:6-8
+          n = (p - v3(e.x, e.y, e.z)) / e.w;                  // c/main.c:229
+          if (type == RT_DIELECTRIC) {
+            B = scatter_dielectric(B, n, m4.w, g);            // attenuation 1 (c/main.c:183)
+            A = p;
+            depth++;
+            done = depth >= job.max_depth;                    // c/main.c:262, 282
+          } else {
+            pending = type == RT_MATTE ? kMatte : kMetal;
+            albedo = v3(m4.x, m4.y, m4.z);
+            fuzz = m4.w;
+          }
+        } else {
+          color = color * sky(B);                             // c/main.c:274-279
+          done = true;
+        }
+        if (done) {
+          args.rad[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
+          finished = true;
+          alive = false;
+        }
+      }
+    }
+    // ---- (3): hand new paths to the lanes without one
     const unsigned long long idle_mask = __ballot(!alive);
     if (idle_mask != 0ull && !exhausted) {
       if (pool_next == pool_end) {
@@ -608,79 +675,38 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
           const uint32_t sample = args.sample0 + s_local;
           g.key = path_key(job.seed, grow * job.nx + col, sample);   // keyed by the global pixel
           g.k = 0;
-          float x, y;
-          pixel_xy(col, job.ny - 1u - grow, job.nx, job.ny, g, x, y);  // rows below = j-1 of c/main.c:466
-          camera_ray(args.cam, x, y, g, A, B);
+          pixel_xy(col, job.ny - 1u - grow, job.nx, job.ny, g, p.x, p.y);  // rows below = j-1 of c/main.c:466
           color = v3(1.0f, 1.0f, 1.0f);
           depth = 0;
           first_hit = -1;
           out_index = s_local * npix + lrow * job.nx + col;
           alive = true;
+          pending = kNewPath;
         }
       }
       pool_next += min((uint32_t)__popcll(idle_mask), avail);
     }
-    if (kBatched) {
-      if (!__syncthreads_or((alive || !exhausted) ? 1 : 0)) break;
-    } else {
-      if (!wave_any(alive)) {
-        if (exhausted) break;
-        continue;   // a chunk of off-image ids: draw again
-      }
-    }
-    // ---- (1)+(2): closest hit
-    unsigned long long c0 = 0, c1 = 0, c2 = 0;
-    if (kProfile) {
-      n_iter++;
-      n_live += (unsigned long long)__popcll(__ballot(alive));
-      c0 = tick();
-    }
-    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0ull};
-    closest_hit_scene<kBatched, kCull, kProfile>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
-    if (kProfile) {
-      c2 = tick();
-      c1 = c2 - h.drain_cycles;
-    }
-
-    // ---- (3): shade
-    {
-      const uint32_t live = (uint32_t)__popcll(__ballot(alive));
-      n_seg += live;
-      n_cand += h.cand;
-      n_tests += (unsigned long long)h.tests * live;
-    }
-    bool finished = false;
-    if (alive) {
-      if (kProfile) {
-        n_own += h.own_groups;
-        n_wave += h.wave_groups;
-      }
-      bool done = false;
-      if (depth == 0) first_hit = h.index;
-      if (h.index >= 0) {
-        float4 e = sc.geom_o[h.index];
-        float4 m4 = sc.mat_o[h.index];
-        V3 ctr = v3(e.x, e.y, e.z);
-        V3 p = A + h.closest * B;              // c/structs.c:6-8
-        V3 n = (p - ctr) / e.w;                // c/main.c:229
-        Material m{sc.type_o[h.index], v3(m4.x, m4.y, m4.z), m4.w};
-        V3 atten, nA, nB;
-        if (scatter(m, A, B, p, n, g, atten, nA, nB)) {
-          A = nA;
-          B = nB;
-          color = atten * color;               // c/main.c:269
-          depth++;
-          done = depth >= job.max_depth;       // c/main.c:262, 282
-        } else {
-          // c/main.c:270-272: the colour becomes 0 and stays 0 whatever the
-          // rest of the reference's loop does with the ray, so the path ends
-          color = v3(0.0f, 0.0f, 0.0f);
-          done = true;
-        }
+    // ---- (4): the point in the unit ball
+    V3 ball = v3(0, 0, 0);
+    if (pending != kNone) ball = unit_ball(g);
+    // ---- (5): shade, second part / camera ray
+    if (pending == kNewPath) {
+      camera_ray_from(args.cam, p.x, p.y, ball, A, B);
+    } else if (pending != kNone) {
+      bool done;
+      if (pending == kMatte) {
+        B = scatter_matte(p, n, ball);
+        done = false;
       } else {
-        color = color * sky(B);                // c/main.c:274-279
-        done = true;
+        // c/main.c:270-272: after an absorbed ray the colour is 0 and stays 0 whatever the rest of the
+        // reference's loop does with the ray, so the path ends
+        done = !scatter_metal(B, n, fuzz, ball, B);
+        if (done) albedo = v3(0.0f, 0.0f, 0.0f);
       }
+      A = p;
+      color = albedo * color;                                 // c/main.c:269
+      depth++;
+      done = done || depth >= job.max_depth;                  // c/main.c:262, 282
       if (done) {
         args.rad[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
         finished = true;
@@ -693,6 +719,14 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
       c_scan += c1 - c0;
       c_drain += c2 - c1;
       c_shade += c3 - c2;
+    }
+    // ---- next trip, or the end: nothing to trace and nothing left to hand out
+    if (kBatched) {
+      work = __syncthreads_or(alive ? 1 : 0) != 0;
+      if (!work && __syncthreads_and(exhausted ? 1 : 0)) break;
+    } else {
+      work = wave_any(alive);
+      if (!work && exhausted) break;
     }
   }
 
