@@ -1,20 +1,25 @@
 // rt_device.hip -- HIP kernels (gfx950) and the C ABI of include/rt_amd.h.
 //
-// Kernel layout.  One lane owns one pixel of an 8x8 pixel block per wave
-// (four waves = one 16x16 block per workgroup) and walks that pixel's samples
-// in order, so the per-pixel float sum has the reference's order
-// (c/main.c:462-469).  A lane whose path ends starts its next sample at once
-// ("persistent lane"); a wave leaves the bounce loop when a ballot shows no
-// lane has work left.
-//
-// Each bounce is (1) a scan of the whole sphere list, staged as 16-byte
-// {cx,cy,cz,K'} entries in LDS and read as wave-wide broadcasts, with the
-// eight-FMA conservative filter of rt_core.h; spheres that pass are appended
-// to a per-lane list in LDS; (2) a drain that runs the reference's exact
-// arithmetic (c/main.c:214-236) on the listed spheres in index order, which
-// gives exactly the hit the reference's linear scan gives because a sphere
-// the filter rejects can never satisfy D > 0; (3) shading (c/main.c:163-211,
-// 258-283).
+// trace_kernel: persistent workgroups take camera paths (pixel, sample) from a
+// global queue; a lane whose path ends is handed the next one, so waves stay
+// full.  One trip of its loop is one bounce of every live lane:
+//   (1) closest hit.  The sphere list sits in LDS in scan order (rt_cluster.h)
+//       as 32-byte sphere pairs read as wave-wide broadcasts.  Per round of two
+//       groups of eight spheres the wave first tests the groups' boxes against
+//       every lane's half line and skips a group no lane can touch; a scanned
+//       group costs 32 packed FMAs (the eight-FMA conservative filter of
+//       rt_core.h on eight spheres).  (lane, sphere) pairs that pass go to a
+//       per-wave list in LDS; the list is drained 64 pairs at a time by
+//       whichever lanes are free, each pair through the reference's exact
+//       arithmetic (c/main.c:214-236) and an LDS 64-bit atomic min on
+//       {t, original index} -- the hit the reference's linear scan returns,
+//       because a sphere the filter rejects can never have D > 0 and the scan's
+//       result does not depend on its order except through that tie-break.
+//   (2)-(5) shading (c/main.c:163-211, 258-283) and new camera rays
+//       (c/structs.c:81-92) around ONE unit-ball rejection loop per trip.
+// resolve_kernel adds each pixel's samples in the reference's order
+// (c/main.c:462-477).  The wf_* kernels are a material-sorted wavefront
+// variant of the same arithmetic, kept for comparison.
 //
 // Compiled with -ffp-contract=off (see rt_core.h).
 #include <hip/hip_runtime.h>
