@@ -43,7 +43,7 @@ def cpu_baseline(nx, ny, scene_name, half_extent, max_depth):
           "small_scene": orc.scene_small}[scene_name]()
     cores = max(1, min(16, os.cpu_count() or 1))
     cam = orc.camera_default(nx, ny)
-    spp = 2 if len(sc) < 2000 else 1
+    spp = 4 if len(sc) < 2000 else 1
     rows = ny if len(sc) < 2000 else max(8, ny // 60)
     row0 = (ny - rows) // 2
     t0 = time.perf_counter()
@@ -148,6 +148,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # bring the clocks up before anything is measured (the first frames after idle run 5-10 % slower);
+    # these frames are neither warm-up steps nor timed steps
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.5:
+        r.render_device(cam, job, tiles.data_ptr())
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     fence()
@@ -195,9 +201,11 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         tests_per_launch = counters["tests"] / args.steps
         achieved = FLOP_PER_TEST * tests_per_launch / (k_ms * 1e-3) / 1e12
-        traffic, traffic_source = hbm_traffic("full" if args.full_scan else "culled") if args.kernel == "mega" else (None, None)
+        # the counter passes were collected on this workload's 64-spp full frame; scaled to this rank's share
+        traffic, traffic_source = (hbm_traffic("full" if args.full_scan else "culled")
+                                   if args.kernel == "mega" and args.workload == "final1080" else (None, None))
         if traffic is not None:
-            traffic *= spp_total / 64.0 * my_rows / ny        # the counters were collected on the 64-spp full frame
+            traffic *= spp_total / 64.0 * my_rows / ny
         out = {
             "metric": "camera paths/sec (Msamples/s) final scene 1920x1080; % FP32 VALU peak",
             "value": total_paths_per_step * args.steps / dt,

@@ -100,3 +100,41 @@ def random_rays(rng, n, spheres=None):
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         A[:k] = (spheres["center"][idx] + spheres["radius"][idx, None] * d).astype(np.float32)
     return np.concatenate([A, B], axis=1).astype(np.float32)
+
+
+def adversarial_rays(rng, spheres, n):
+    """Tangent and near-tangent rays, rays leaving a surface, huge and tiny directions."""
+    idx = rng.integers(0, len(spheres), n)
+    c, r = spheres["center"][idx].astype(np.float64), spheres["radius"][idx].astype(np.float64)
+    A = rng.uniform(-15, 15, (n, 3))
+    A[:, 1] = rng.uniform(0, 4, n)
+    to_c = c - A
+    dist = np.linalg.norm(to_c, axis=1)
+    w = to_c / dist[:, None]
+    t1 = np.cross(w, rng.normal(size=(n, 3)))
+    t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    # aim at a point displaced r*(1+eps) sideways from the centre: grazing by construction
+    eps = rng.choice([0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3], n)
+    target = c + t1 * (r * (1 + eps))[:, None]
+    B = (target - A) * rng.choice([0.01, 1, 1, 40], n)[:, None]
+    return np.concatenate([A, B], axis=1).astype(np.float32)
+
+
+def leaving_rays(rng, spheres, n):
+    """Rays that start on, just inside or just outside a sphere and head away from it, along it or barely
+    towards it, with directions from 1e-6 to 1e3 long and some components exactly zero: the cases in which
+    'the group is behind the ray' is a close call."""
+    idx = rng.integers(0, len(spheres), n)
+    c, r = spheres["center"][idx].astype(np.float64), spheres["radius"][idx].astype(np.float64)
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    off = rng.choice([0, 1e-7, -1e-7, 1e-6, -1e-6, 1e-4, -1e-4, 1e-2], n)
+    A = c + nrm * (r * (1 + off))[:, None]
+    tang = np.cross(nrm, rng.normal(size=(n, 3)))
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True)
+    lean = rng.choice([0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3, 0.3, -0.3, 1.0], n)   # > 0 leaves the sphere
+    B = tang * rng.uniform(0, 1, n)[:, None] + nrm * lean[:, None]
+    B *= rng.choice([1e-6, 1e-4, 1e-2, 1, 1, 1e3], n)[:, None]
+    B[rng.random(n) < 0.05, rng.integers(0, 3)] = 0.0
+    keep = np.linalg.norm(A, axis=1) < 31.0
+    return np.concatenate([A, B], axis=1).astype(np.float32)[keep]

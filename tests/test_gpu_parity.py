@@ -11,7 +11,7 @@ in 2^27 dielectric scatters.
 import numpy as np
 import pytest
 
-from conftest import as_oracle_scene, load_golden_npz, random_rays
+from conftest import adversarial_rays, as_oracle_scene, leaving_rays, load_golden_npz, random_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +52,31 @@ def test_closest_hit_equals_reference_scan(renderer, rt, oracle, scene):
     for i, r in enumerate(rays):
         oi, ot, _, _ = oracle.hit_scene(osc, r[:3], r[3:])
         assert oi == idx[i], (i, oi, idx[i])
+        if oi >= 0:
+            hits += 1
+            assert ot.tobytes() == t[i].tobytes()
+    assert hits > 1000
+
+
+@pytest.mark.parametrize("scene", ["small_scene", "random_scene"])
+def test_closest_hit_close_calls(renderer, rt, oracle, scene):
+    """Rays for which 'this group is behind / beside the ray' is a close call, rays the kernel does not cull
+    at all (origin beyond 32, a zero direction component, tiny directions) and grazing rays."""
+    sc = getattr(rt, scene)()
+    renderer.upload(sc)
+    rng = np.random.default_rng(21)
+    leave = leaving_rays(rng, sc, 3000)
+    far = random_rays(rng, 600, sc)
+    far[:, :3] *= 4.0
+    axis = random_rays(rng, 600, sc)
+    axis[np.arange(600), 3 + rng.integers(0, 3, 600)] = 0.0
+    rays = np.concatenate([leave, far, axis, adversarial_rays(rng, sc, 1500)]).astype(np.float32)
+    idx, t = renderer.closest_hit(rays)
+    osc = as_oracle_scene(sc)
+    hits = 0
+    for i, r in enumerate(rays):
+        oi, ot, _, _ = oracle.hit_scene(osc, r[:3], r[3:])
+        assert oi == idx[i], (i, oi, idx[i], r)
         if oi >= 0:
             hits += 1
             assert ot.tobytes() == t[i].tobytes()
