@@ -21,7 +21,10 @@
 // i runs within rho_i of its centre), and the second term is the slack of the
 // half-line argument.  The half extents are then widened by
 // 2^-20 (|c_k| + 32) + 2^-19 h_k for the rounding of the slab arithmetic.
-// Rays that start farther out than 32 are not culled.
+// Rays that start farther out than 32 are not culled.  Four consecutive
+// groups form a super-group whose box (the box around the four, widened once
+// more for its own slab arithmetic) is tested first; a wave skips the four
+// box tests of a super-group no lane's ray can touch.
 //
 // Scenes like the reference's are flat fields of small spheres on one huge
 // one; boxes around Morton neighbours are flat too, so most rays that fly over
@@ -41,14 +44,16 @@
 namespace rtcluster {
 
 constexpr int kGroup = 8;                      // spheres per group = one chunk of the scan
+constexpr int kSuper = 4;                      // groups per super-group (a box of its own, tested first)
 constexpr double kCullOriginLimit = 32.0;      // |A| above this: no culling for that ray (rtcore::kBoxOriginLimit2)
 constexpr double kLargeFactor = 3.0;           // radius > this * median radius: scanned by every ray
 
 struct Layout {
   std::vector<uint32_t> order;        // scan position -> original index, 0xffffffff for a pad
   std::vector<rtcore::GroupBox> boxes;  // one per group; h = +1e30 means "always scan", -1e30 "never"
+  std::vector<rtcore::GroupBox> supers; // one per kSuper consecutive groups: the box around their boxes
   std::vector<uint8_t> real_in_group; // real (non-pad) spheres per group
-  uint32_t n_scan = 0;                // = order.size(), a multiple of 2*kGroup
+  uint32_t n_scan = 0;                // = order.size(), a multiple of 2*kSuper*kGroup (a pair of super-groups)
 };
 
 inline float round_up_to_float(double v) {
@@ -127,11 +132,42 @@ inline Layout build_layout(const rt_sphere *s, size_t n) {
     }
     L.boxes.push_back(rtcore::GroupBox{c[0], c[1], c[2], h[0], h[1], h[2]});
   };
+  // centre (as the kernel will see it) and widened half extents of the box [lo, hi]
+  auto widened_box = [&](const double lo[3], const double hi[3]) {
+    float c[3], h[3];
+    for (int d = 0; d < 3; ++d) {
+      c[d] = (float)(0.5 * (lo[d] + hi[d]));
+      const double h0 = std::max(hi[d] - (double)c[d], (double)c[d] - lo[d]);
+      h[d] = round_up_to_float((h0 + std::ldexp(std::fabs((double)c[d]) + kCullOriginLimit, -20)) * (1.0 + std::ldexp(1.0, -19)));
+    }
+    return rtcore::GroupBox{c[0], c[1], c[2], h[0], h[1], h[2]};
+  };
 
   for (size_t k = 0; k < large.size(); k += kGroup) emit_group(&large[k], std::min<size_t>(kGroup, large.size() - k), true);
   for (size_t k = 0; k < regular.size(); k += kGroup)
     emit_group(&regular[k], std::min<size_t>(kGroup, regular.size() - k), false);
-  if (L.boxes.size() % 2) emit_group(nullptr, 0, false);   // rounds are two groups
+  while (L.boxes.size() % (2 * kSuper)) emit_group(nullptr, 0, false);   // whole pairs of super-groups
+  for (size_t g0 = 0; g0 < L.boxes.size(); g0 += kSuper) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    bool always = false, any = false;
+    for (size_t g = g0; g < g0 + kSuper; ++g) {
+      const rtcore::GroupBox &b = L.boxes[g];
+      if (b.hx > 1.0e29f) always = true;
+      if (b.hx > 1.0e29f || b.hx < 0.0f) continue;
+      any = true;
+      const float c[3] = {b.cx, b.cy, b.cz}, h[3] = {b.hx, b.hy, b.hz};
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = std::min(lo[d], (double)c[d] - (double)h[d]);
+        hi[d] = std::max(hi[d], (double)c[d] + (double)h[d]);
+      }
+    }
+    if (always || !any) {
+      const float h = always ? 1.0e30f : -1.0e30f;
+      L.supers.push_back(rtcore::GroupBox{0.0f, 0.0f, 0.0f, h, h, h});
+    } else {
+      L.supers.push_back(widened_box(lo, hi));
+    }
+  }
   L.n_scan = (uint32_t)L.order.size();
   return L;
 }

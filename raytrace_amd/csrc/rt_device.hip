@@ -64,6 +64,7 @@ constexpr int kNumCounters = 13;
 struct DeviceScene {
   const float4 *filter;   // n_pad entries, sphere pairs {cx0,cx1,cy0,cy1},{cz0,cz1,K'0,K'1}; pads never pass
   const float4 *boxes;    // 3 entries per round of two groups: {cx0,cx1,cy0,cy1},{cz0,cz1,hx0,hx1},{hy0,hy1,hz0,hz1}
+  const float4 *sboxes;   // 3 entries per pair of super-groups (64 spheres), same layout as boxes
   const float4 *exact;    // n_pad entries {cx, cy, cz, r*r}
   const uint32_t *orig;   // n_pad entries: index in the caller's list (ties go to the lowest), ~0 for pads
   // for shading, in the CALLER's order (n entries):
@@ -73,6 +74,8 @@ struct DeviceScene {
   const uint32_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (byte 0, byte 1); dwords so
                                // that the wave-uniform read is a scalar load
   uint32_t n, n_pad;
+  uint32_t n_full;        // scan positions up to the last real sphere, rounded up to a round (16): what a
+                          // scan without culling has to visit (the rest is padding)
 };
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
@@ -123,6 +126,7 @@ constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a chunk ad
 struct ScanLds {
   float4 *pairs;
   float4 *boxes;                 // 3 per round (16 spheres)
+  float4 *sboxes;                // 3 per pair of super-groups (64 spheres)
   float4 *rays;                  // 3 per lane: {A, a}, {B, tmin}, {1/a as a double, -, -}
   unsigned long long *best;      // 1 per lane
   uint32_t *wlist;               // kWaveListCap per wave: (owner lane << 16) | scan position
@@ -132,7 +136,8 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
   ScanLds l;
   l.pairs = reinterpret_cast<float4 *>(smem);
   l.boxes = l.pairs + entries;
-  l.rays = l.boxes + 3u * (entries / 16u);
+  l.sboxes = l.boxes + 3u * (entries / 16u);
+  l.rays = l.sboxes + 3u * (entries / 64u);
   l.best = reinterpret_cast<unsigned long long *>(l.rays + 3 * kBlockThreads);
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
   return l;
@@ -142,6 +147,7 @@ __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds
                                             uint32_t tid) {
   for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[i] = sc.filter[base + i];
   for (uint32_t i = tid; i < 3u * (count / 16u); i += kBlockThreads) lds.boxes[i] = sc.boxes[3u * (base / 16u) + i];
+  for (uint32_t i = tid; i < 3u * (count / 64u); i += kBlockThreads) lds.sboxes[i] = sc.sboxes[3u * (base / 64u) + i];
 }
 
 // What a wave carries through one scan.
@@ -394,7 +400,7 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
 // every group; lanes without a ray take none.
 template <bool kCull>
 __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, const float4 *lds_boxes,
-                                           uint32_t base, uint32_t count, const FilterRayP &fr, const BoxRayP &br,
+                                           const float4 *lds_sboxes, uint32_t base, uint32_t count, const FilterRayP &fr, const BoxRayP &br,
                                            bool alive, bool uncullable, WaveScan &w, HitState &h) {
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
   if (!kCull) {
@@ -446,20 +452,39 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
       tests += real >> 8;
     }
   };
-  // Two rounds per trip with two sets of box registers, each read one round before its use, so that
-  // no register is copied; a read past the last round is redirected to round 0 and never used.
-  float4 qa[3] = {lds_boxes[0], lds_boxes[1], lds_boxes[2]}, qb[3];
-  for (uint32_t i0 = 0; i0 < count; i0 += 2 * kDrainEvery) {
-    const uint32_t ib = 3u * ((i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u) >> 4);
-    qb[0] = lds_boxes[ib];
-    qb[1] = lds_boxes[ib + 1];
-    qb[2] = lds_boxes[ib + 2];
-    round(qa, i0);
-    const uint32_t ia = 3u * ((i0 + 2 * kDrainEvery < count ? i0 + 2 * kDrainEvery : 0u) >> 4);
-    qa[0] = lds_boxes[ia];
-    qa[1] = lds_boxes[ia + 1];
-    qa[2] = lds_boxes[ia + 2];
-    if (i0 + kDrainEvery < count) round(qb, i0 + kDrainEvery);
+  // Super-groups first: the boxes of a pair of super-groups (64 spheres) in one packed evaluation, read
+  // one pair ahead in a second register set; only a super-group some lane's ray can touch has its two
+  // rounds (four group boxes) looked at.
+  auto super_pair = [&](const float4 (&sq)[3], uint32_t i0) {
+    bool spass[2];
+    box_pair(br, sq, spass);
+    const unsigned long long s0 = (__ballot(spass[0]) & live_mask) | all_mask, s1 = (__ballot(spass[1]) & live_mask) | all_mask;
+    tests += 2u;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 2u; ++k) {
+      if ((k ? s1 : s0) != 0ull) {
+        asm volatile("");
+        const uint32_t j0 = i0 + 2u * kDrainEvery * k;
+        const uint32_t ib = 3u * (j0 >> 4);
+#pragma unroll 1
+        for (uint32_t r = 0; r < 2u; ++r) {
+          const float4 q[3] = {lds_boxes[ib + 3u * r], lds_boxes[ib + 3u * r + 1], lds_boxes[ib + 3u * r + 2]};
+          round(q, j0 + kDrainEvery * r);
+        }
+      }
+    }
+  };
+  constexpr uint32_t kPairSpan = 4u * kDrainEvery;   // spheres per pair of super-groups
+  float4 sq[3] = {lds_sboxes[0], lds_sboxes[1], lds_sboxes[2]};
+#pragma unroll 1
+  for (uint32_t i0 = 0; i0 < count; i0 += kPairSpan) {
+    // the next pair's boxes are read before this pair is worked on (the read past the end is redirected)
+    const uint32_t in = 3u * ((i0 + kPairSpan < count ? i0 + kPairSpan : 0u) >> 6);
+    const float4 n0 = lds_sboxes[in], n1 = lds_sboxes[in + 1], n2 = lds_sboxes[in + 2];
+    super_pair(sq, i0);
+    sq[0] = n0;
+    sq[1] = n1;
+    sq[2] = n2;
   }
   h.tests += tests;
 }
@@ -498,10 +523,12 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       __syncthreads();
       stage_batch(sc, lds, base, count, tid);
       __syncthreads();
-      scan_batch<kCull>(sc, lds.pairs, lds.boxes, base, count, fr, br, alive, uncullable, w, h);
+      // (without culling the trailing padding is not visited)
+      const uint32_t span = kCull ? count : (sc.n_full > base ? min(count, sc.n_full - base) : 0u);
+      scan_batch<kCull>(sc, lds.pairs, lds.boxes, lds.sboxes, base, span, fr, br, alive, uncullable, w, h);
     }
   } else {
-    scan_batch<kCull>(sc, lds.pairs, lds.boxes, 0u, sc.n_pad, fr, br, alive, uncullable, w, h);
+    scan_batch<kCull>(sc, lds.pairs, lds.boxes, lds.sboxes, 0u, kCull ? sc.n_pad : sc.n_full, fr, br, alive, uncullable, w, h);
   }
   if (!kCull) h.tests += sc.n;
   const unsigned long long d0 = kProfile ? tick() : 0ull;
@@ -1096,11 +1123,11 @@ struct rt_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events[kHistory];
   int trace_used[kHistory] = {};
   long renders = 0;
-  DevBuf<float4> filter, boxes, exact, geom_o, mat_o;
+  DevBuf<float4> filter, boxes, sboxes, exact, geom_o, mat_o;
   DevBuf<int32_t> type_o;
   DevBuf<uint32_t> orig;
   DevBuf<uint32_t> round_real;
-  uint32_t n = 0, n_pad = 0;
+  uint32_t n = 0, n_pad = 0, n_full = 0;
   DevBuf<unsigned long long> counters;
   DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
   DevBuf<float4> rad;                // per-path radiance of one sample batch
@@ -1135,11 +1162,11 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->round_real.p, c->n, c->n_pad};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->round_real.p, c->n, c->n_pad, c->n_full};
 }
 
 size_t scan_lds_bytes(uint32_t entries) {
-  return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u) * sizeof(float4) +  // pair image, boxes
+  return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u) * sizeof(float4) +  // pair image, boxes
          (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
          (size_t)(kBlockThreads / 64) * kWaveListCap * sizeof(uint32_t);                    // wave lists
 }
@@ -1351,6 +1378,7 @@ int rt_ctx_destroy(rt_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->filter.release();
   c->boxes.release();
+  c->sboxes.release();
   c->orig.release();
   c->round_real.release();
   c->exact.release();
@@ -1414,7 +1442,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   const uint32_t n_pad = L.n_scan;
   static_assert(rtcluster::kGroup == kChunk, "one group per chunk");
   if (n_pad > kMaxSpheres) return fail(RT_ERR_LIMIT, "too many spheres after padding");
-  std::vector<float4> filter(n_pad), exact(n_pad), boxes(3 * (n_pad / 16)), geom_o(n), mat_o(n);
+  std::vector<float4> filter(n_pad), exact(n_pad), boxes(3 * (n_pad / 16)), sboxes(3 * (n_pad / 64)), geom_o(n), mat_o(n);
   std::vector<int32_t> type_o(n);
   std::vector<uint32_t> round_real(n_pad / 16);
   std::vector<FilterSphere> fs(n_pad);
@@ -1447,14 +1475,21 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     boxes[3 * (g / 2) + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
     round_real[g / 2] = (uint32_t)(L.real_in_group[g] | (L.real_in_group[g + 1] << 8));
   }
+  for (uint32_t q = 0; q < n_pad / 64; ++q) {
+    const GroupBox &b0 = L.supers[2 * q], &b1 = L.supers[2 * q + 1];
+    sboxes[3 * q] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
+    sboxes[3 * q + 1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
+    sboxes[3 * q + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
+  }
   int rc;
-  if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->exact.reserve(n_pad)) ||
+  if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(3 * (n_pad / 64))) || (rc = c->exact.reserve(n_pad)) ||
       (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
       (rc = c->orig.reserve(n_pad)) || (rc = c->round_real.reserve(n_pad / 16)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->boxes.p, boxes.data(), 3 * (n_pad / 16) * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->sboxes.p, sboxes.data(), 3 * (n_pad / 64) * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->exact.p, exact.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->geom_o.p, geom_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
@@ -1463,6 +1498,10 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
   c->n_pad = n_pad;
+  uint32_t last_real = 0;
+  for (uint32_t p = 0; p < n_pad; ++p)
+    if (L.order[p] != 0xffffffffu) last_real = p;
+  c->n_full = (last_real / 16u + 1u) * 16u;
   return RT_OK;
 }
 

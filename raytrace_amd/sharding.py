@@ -15,12 +15,20 @@ class FrameShards:
         self.jobs = [interleaved_job(nx, ny, nsamples, r, world, tile_rows, **job_kw) for r in range(world)]
         self.rows = [job_row_indices(j) for j in self.jobs]
         self.max_rows = max((len(r) for r in self.rows), default=0)
+        self._row_index = {}     # (rank, device) -> index tensor, built once
 
     def job(self, rank):
         return self.jobs[rank]
 
     def rows_of(self, rank):
         return self.rows[rank]
+
+    def row_index(self, rank, device):
+        import torch
+        key = (rank, str(device))
+        if key not in self._row_index:
+            self._row_index[key] = torch.as_tensor(self.rows[rank], device=device)
+        return self._row_index[key]
 
     def check(self):
         seen = np.concatenate(self.rows) if self.rows else np.zeros(0, np.int64)
@@ -47,7 +55,7 @@ def gather_frame(shards, my_tiles, rank, frame=None, gathered=None):
     if frame is None:
         frame = torch.zeros((shards.ny, shards.nx, 3), dtype=my_tiles.dtype, device=my_tiles.device)
     for q in range(world):
-        idx = torch.as_tensor(shards.rows_of(q), device=my_tiles.device)
+        idx = shards.row_index(q, my_tiles.device)
         if len(idx):
             frame[idx] = gathered[q][: len(idx)]
     return frame

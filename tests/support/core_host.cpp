@@ -96,7 +96,8 @@ uint64_t core_cull_check(const rt_sphere *s, size_t n, const float *rays, size_t
     const double inv_a = 1.0 / (double)a;
     for (size_t g = 0; g < L.boxes.size(); g++) {
       tot++;
-      if (box_pass(br, L.boxes[g])) continue;
+      // culled when the ray misses the group's box or the box of its super-group
+      if (box_pass(br, L.boxes[g]) && box_pass(br, L.supers[g / rtcluster::kSuper])) continue;
       cul++;
       for (int k = 0; k < rtcluster::kGroup; k++) {
         const uint32_t i = L.order[g * rtcluster::kGroup + k];
@@ -124,7 +125,9 @@ int core_layout_check(const rt_sphere *s, size_t n, uint32_t *n_scan, uint32_t *
     }
   for (size_t i = 0; i < n; i++)
     if (seen[i] != 1) return 2;
-  if (L.n_scan % 16 || L.boxes.size() * 8 != L.n_scan || L.real_in_group.size() != L.boxes.size()) return 3;
+  if (L.n_scan % 64 || L.boxes.size() * 8 != L.n_scan || L.real_in_group.size() != L.boxes.size() ||
+      L.supers.size() * rtcluster::kSuper != L.boxes.size())
+    return 3;
   *n_scan = L.n_scan;
   *n_groups = (uint32_t)L.boxes.size();
   return 0;
