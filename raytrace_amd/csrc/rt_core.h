@@ -99,15 +99,22 @@ RT_HD double next_uniform(Rng &g) {
 // FLT_EPSILON; for a correctly rounded square root sqrtf(s) < 1 exactly when
 // s < 1 (the float below 1 has a root that rounds below 1) and sqrtf(s) <
 // 2^-23 exactly when s < 2^-46, so the loop tests s itself.
+// one attempt: three draws, the candidate, and whether the loop would keep it
+RT_HD bool unit_ball_try(Rng &g, V3 &u) {
+  float ux = (float)next_uniform(g);
+  float uy = (float)next_uniform(g);
+  float uz = (float)next_uniform(g);
+  // 2*x - 1 (c/vec.c:67-68): the product is exact, so one fused operation rounds like the two
+  u = v3(rt_fma(2.0f, ux, -1.0f), rt_fma(2.0f, uy, -1.0f), rt_fma(2.0f, uz, -1.0f));
+  float s = u.x * u.x + u.y * u.y + u.z * u.z;
+  return s < 1.0f && !(s < 1.4210854715202004e-14f);   // 2^-46
+}
+
 RT_HD V3 unit_ball(Rng &g) {
-  for (;;) {
-    float ux = (float)next_uniform(g);
-    float uy = (float)next_uniform(g);
-    float uz = (float)next_uniform(g);
-    V3 u = 2.0f * v3(ux, uy, uz) - v3(1.0f, 1.0f, 1.0f);
-    float s = u.x * u.x + u.y * u.y + u.z * u.z;
-    if (s < 1.0f && !(s < 1.4210854715202004e-14f)) return u;   // 2^-46
+  V3 u;
+  while (!unit_ball_try(g, u)) {
   }
+  return u;
 }
 
 // ------------------------------------------------------------------ camera
