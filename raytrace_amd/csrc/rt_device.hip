@@ -1435,6 +1435,10 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   for (size_t i = 0; i < n; ++i) {
     if (spheres[i].type < RT_MATTE || spheres[i].type > RT_DIELECTRIC)
       return fail(RT_ERR_ARG, "unknown material type in sphere " + std::to_string(i));
+    // (the scan order is built by sorting on the centres)
+    if (!std::isfinite(spheres[i].center[0]) || !std::isfinite(spheres[i].center[1]) || !std::isfinite(spheres[i].center[2]) ||
+        !std::isfinite(spheres[i].radius))
+      return fail(RT_ERR_ARG, "centre or radius of sphere " + std::to_string(i) + " is not finite");
   }
   RT_HIP(hipSetDevice(c->device));
   // scan order and group bounds (rt_cluster.h); everything below is in scan order
