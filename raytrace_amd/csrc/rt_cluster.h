@@ -11,25 +11,22 @@
 //
 // Each group of regular spheres has an axis-aligned box; a ray that misses the
 // box on its half line t >= 0 skips the group (test and proof obligations in
-// rt_core.h, "group box test").  The box of a group contains, for each member,
-// the ball of radius
-//   rho_i + 2^-21 (32 + |C_i| + r_i),   rho_i^2 = r_i^2 + 1.375 kappa (32^2 + |C_i|^2 + r_i^2)
-// where rho_i bounds the distance at which a line can still make the
-// reference's discriminant positive for an origin with |A| <= 32 (kappa = 2^-17
-// is the margin of the conservative sphere filter, which covers the rounding
-// of the reference's own discriminant; a line that passes the filter of sphere
-// i runs within rho_i of its centre), and the second term is the slack of the
-// half-line argument.  The half extents are then widened by
-// 2^-20 (|c_k| + 32) + 2^-19 h_k for the rounding of the slab arithmetic.
-// Rays that start farther out than 32 are not culled.  Four consecutive
-// groups form a super-group whose box (the box around the four, widened once
-// more for its own slab arithmetic) is tested first; a wave skips the four
-// box tests of a super-group no lane's ray can touch.
+// rt_core.h, "group box test").  The stored box of a group contains, for each
+// member, the ball of radius
+//   r_i + a_i + 2^-21 (|C_i| + r_i),   a_i = 1.375 kappa (|C_i|^2 + r_i^2) / (2 r_i)
+// (kappa = 2^-17 is the margin of the conservative sphere filter), its half
+// extents widened by 2^-20 (|c_k| + 1) + 2^-19 h_k for the rounding of the slab
+// arithmetic.  What the test needs beyond that grows with the ray's distance
+// from the world origin and is applied per ray as a factor 1 + sigma0 + sigma1
+// |A|^2 on the half extents; this file computes sigma0 and sigma1.  Four
+// consecutive groups form a super-group whose box (the box around the four,
+// widened once more for its own slab arithmetic) is tested first; a wave skips
+// the four box tests of a super-group no lane's ray can touch.
 //
 // Scenes like the reference's are flat fields of small spheres on one huge
 // one; boxes around neighbours are flat too, so most rays that fly over a
-// group miss its box.  Spheres much larger than the median go to groups that
-// every ray scans.
+// group miss its box.  Spheres much larger than the median (and degenerate
+// ones, radius below 2^-16) go to groups that every ray scans.
 #pragma once
 
 #include <algorithm>
@@ -45,7 +42,7 @@ namespace rtcluster {
 
 constexpr int kGroup = 8;                      // spheres per group = one chunk of the scan
 constexpr int kSuper = 4;                      // groups per super-group (a box of its own, tested first)
-constexpr double kCullOriginLimit = 32.0;      // |A| above this: no culling for that ray (rtcore::kBoxOriginLimit2)
+constexpr double kTinyRadius = 1.0 / 65536.0;   // radius below this: scanned by every ray (keeps sigma1 bounded)
 constexpr double kLargeFactor = 3.0;           // radius > this * median radius: scanned by every ray
 
 struct Layout {
@@ -54,6 +51,7 @@ struct Layout {
   std::vector<rtcore::GroupBox> supers; // one per kSuper consecutive groups: the box around their boxes
   std::vector<uint8_t> real_in_group; // real (non-pad) spheres per group
   uint32_t n_scan = 0;                // = order.size(), a multiple of 2*kSuper*kGroup (a pair of super-groups)
+  float sigma0 = 0.0f, sigma1 = 0.0f; // per-ray growth of the half extents: 1 + sigma0 + sigma1 |A|^2 (rt_core.h)
 };
 
 inline float round_up_to_float(double v) {
@@ -70,7 +68,8 @@ inline Layout build_layout(const rt_sphere *s, size_t n) {
   std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
   const double median = sorted[n / 2];
   std::vector<uint32_t> large, regular;
-  for (size_t i = 0; i < n; ++i) ((double)radii[i] > kLargeFactor * median ? large : regular).push_back((uint32_t)i);
+  for (size_t i = 0; i < n; ++i)
+    ((double)radii[i] > kLargeFactor * median || !((double)radii[i] >= kTinyRadius) ? large : regular).push_back((uint32_t)i);
 
   // Order of the regular spheres: recursive median split along the longest axis of the centres, the left
   // part always a whole number of groups, until a part is one group.  Consecutive groups are then
@@ -109,6 +108,17 @@ inline Layout build_layout(const rt_sphere *s, size_t n) {
     regular.swap(ordered);
   }
 
+  // centre (as the kernel will see it) and widened half extents of the box [lo, hi]
+  auto widened_box = [&](const double lo[3], const double hi[3]) {
+    float c[3], h[3];
+    for (int d = 0; d < 3; ++d) {
+      c[d] = (float)(0.5 * (lo[d] + hi[d]));
+      const double h0 = std::max(hi[d] - (double)c[d], (double)c[d] - lo[d]);
+      h[d] = round_up_to_float((h0 + std::ldexp(std::fabs((double)c[d]) + 1.0, -20)) * (1.0 + std::ldexp(1.0, -19)));
+    }
+    return rtcore::GroupBox{c[0], c[1], c[2], h[0], h[1], h[2]};
+  };
+  double b_max = 0.0, h_min = 1e300;
   auto emit_group = [&](const uint32_t *idx, size_t cnt, bool always) {
     for (size_t k = 0; k < (size_t)kGroup; ++k) L.order.push_back(k < cnt ? idx[k] : 0xffffffffu);
     L.real_in_group.push_back((uint8_t)cnt);
@@ -118,38 +128,23 @@ inline Layout build_layout(const rt_sphere *s, size_t n) {
       return;
     }
     const double kap = rtcore::kFilterKappa;
-    const double A2 = kCullOriginLimit * kCullOriginLimit;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (size_t k = 0; k < cnt; ++k) {
       const rt_sphere &m = s[idx[k]];
       double ci2 = 0;
       for (int d = 0; d < 3; ++d) ci2 += (double)m.center[d] * m.center[d];
-      const double r2 = (double)m.radius * m.radius;
-      const double rho = std::sqrt(r2 + 1.375 * kap * (A2 + ci2 + r2));
-      const double reach = rho + std::ldexp(kCullOriginLimit + std::sqrt(ci2) + std::fabs((double)m.radius), -21);
+      const double r = (double)m.radius, r2 = r * r;
+      const double a_i = 1.375 * kap * (ci2 + r2) / (2.0 * r);
+      b_max = std::max(b_max, 1.375 * kap / (2.0 * r));
+      const double reach = r + a_i + std::ldexp(std::sqrt(ci2) + r, -21);
       for (int d = 0; d < 3; ++d) {
         lo[d] = std::min(lo[d], (double)m.center[d] - reach);
         hi[d] = std::max(hi[d], (double)m.center[d] + reach);
       }
     }
-    float c[3], h[3];
-    for (int d = 0; d < 3; ++d) {
-      c[d] = (float)(0.5 * (lo[d] + hi[d]));   // the centre the kernel will see
-      const double h0 = std::max(hi[d] - (double)c[d], (double)c[d] - lo[d]);
-      const double widened = (h0 + std::ldexp(std::fabs((double)c[d]) + kCullOriginLimit, -20)) * (1.0 + std::ldexp(1.0, -19));
-      h[d] = round_up_to_float(widened);
-    }
-    L.boxes.push_back(rtcore::GroupBox{c[0], c[1], c[2], h[0], h[1], h[2]});
-  };
-  // centre (as the kernel will see it) and widened half extents of the box [lo, hi]
-  auto widened_box = [&](const double lo[3], const double hi[3]) {
-    float c[3], h[3];
-    for (int d = 0; d < 3; ++d) {
-      c[d] = (float)(0.5 * (lo[d] + hi[d]));
-      const double h0 = std::max(hi[d] - (double)c[d], (double)c[d] - lo[d]);
-      h[d] = round_up_to_float((h0 + std::ldexp(std::fabs((double)c[d]) + kCullOriginLimit, -20)) * (1.0 + std::ldexp(1.0, -19)));
-    }
-    return rtcore::GroupBox{c[0], c[1], c[2], h[0], h[1], h[2]};
+    const rtcore::GroupBox box = widened_box(lo, hi);
+    h_min = std::min(h_min, (double)std::min(box.hx, std::min(box.hy, box.hz)));
+    L.boxes.push_back(box);
   };
 
   for (size_t k = 0; k < large.size(); k += kGroup) emit_group(&large[k], std::min<size_t>(kGroup, large.size() - k), true);
@@ -178,6 +173,10 @@ inline Layout build_layout(const rt_sphere *s, size_t n) {
     }
   }
   L.n_scan = (uint32_t)L.order.size();
+  if (h_min < 1e299) {   // (else there is nothing to cull)
+    L.sigma0 = round_up_to_float(std::ldexp(1.0, -19) / h_min);
+    L.sigma1 = round_up_to_float((b_max + std::ldexp(1.0, -19)) / h_min);
+  }
   return L;
 }
 

@@ -256,25 +256,35 @@ RT_HD f32x2 filter_discriminant2(const FilterRay2 &f, f32x2 cx, f32x2 cy, f32x2 
 // Spheres are scanned in groups (rt_cluster.h); a ray skips a group when it
 // misses the group's axis-aligned box, tested on the half line t >= 0 with the
 // slab method in centre / half-extent form:
-//   m_k = (c_k - A_k) / B_k,  near_k = m_k - h_k / |B_k|,  far_k = m_k + h_k / |B_k|
+//   m_k = (c_k - A_k) / B_k,  near_k = m_k - H_k / |B_k|,  far_k = m_k + H_k / |B_k|
 //   pass  <=>  min_k far_k >= max(max_k near_k, 0)
-// The test only has to be conservative: a sphere the reference reports as hit
-// (c/main.c:214-236 with t > tmin >= 0) must lie in a group that passes.
-//  * If the reference's discriminant is positive the true line passes within
-//    rho_i of the centre (rt_cluster.h), at parameter t* = -b/a.  If it also
-//    reports a root t > 0 then either its computed b is negative, so the true
-//    t* is above -4u |A-C| / |B| and the origin is within 2^-22 (|A|+|C|) of a
-//    point of that ball; or b >= 0 and the larger root is positive, which
-//    needs sqrt(D) > b, i.e. a*c <= 2u b^2, i.e. |A-C| <= r (1 + 8u): the origin
-//    is inside the ball.  Either way the half line t >= 0 meets the ball of
-//    radius rho_i + 2^-21 (|A| + |C_i| + r_i), which the box contains.
+// with H_k = h_k (1 + sigma), h_k the stored half extent and sigma = sigma0 +
+// sigma1 |A|^2 a per-ray factor (folded into 1/|B_k| once per ray, so the test
+// costs the same as with fixed boxes).  The test only has to be conservative:
+// a sphere the reference reports as hit (c/main.c:214-236 with t > tmin >= 0)
+// must lie in a group that passes.
+//  * If the reference's discriminant is positive, the sphere passes the
+//    conservative filter above, whose margin puts the true line within rho_i
+//    of the centre, rho_i^2 = r_i^2 + 1.375 kappa (|A|^2 + |C_i|^2 + r_i^2), hence
+//    rho_i <= r_i + a_i + b_i |A|^2,  a_i = 1.375 kappa (|C_i|^2 + r_i^2) / (2 r_i),
+//    b_i = 1.375 kappa / (2 r_i).  The closest approach is at t* = -b/a.
+//  * If the reference also reports a root t > 0 then either its computed b is
+//    negative, so the true t* is above -4u |A-C| / |B| and the origin is within
+//    2^-22 (|A|+|C|) of a point of that ball; or b >= 0 and the larger root is
+//    positive, which needs sqrt(D) > b, i.e. a*c <= 2u b^2, i.e. |A-C| <= r (1 +
+//    8u): the origin is inside the ball.  Either way the half line t >= 0 meets
+//    the ball of radius rho_i + 2^-21 (|A| + |C_i| + r_i).
+//  * The stored box holds the part of that radius that does not depend on the
+//    ray, r_i + a_i + 2^-21 (|C_i| + r_i); the rest, b_i |A|^2 + 2^-21 |A|, is
+//    below h_min sigma when sigma0 = 2^-19 / h_min, sigma1 = (max b_i + 2^-19) /
+//    h_min (h_min: the smallest stored half extent of the scene).
 //  * The float evaluation below (one-ulp reciprocal, three roundings per slab)
-//    is off by less than 0.75 * 2^-21 (h_k + |c_k| + |A_k|) / |B_k| per bound;
-//    the boxes are widened by more than that (rt_cluster.h), so the computed
-//    interval of every axis contains the true one.
-// Rays outside the range the margins were derived for -- |A|^2 >= 1023, a
-// direction component below 2^-30 in magnitude (its reciprocal would leave the
-// range), |B|^2 >= 2^40 -- are not culled at all (box_ray_in_range).
+//    is off by less than 0.75 * 2^-21 (H_k + |c_k| + |A_k|) / |B_k| per bound;
+//    the stored half extents are widened for the first two terms
+//    (rt_cluster.h) and sigma has room for the third.
+// Rays with a direction component below 2^-30 in magnitude (its reciprocal
+// would leave the range), |B|^2 >= 2^40 or |A|^2 >= 2^40 are not culled at all
+// (box_ray_in_range).
 
 struct GroupBox {  // centre and half extents; h = +1e30: always scanned, h = -1e30: never (padding)
   float cx, cy, cz, hx, hy, hz;
@@ -283,16 +293,15 @@ struct GroupBox {  // centre and half extents; h = +1e30: always scanned, h = -1
 struct BoxRay {
   float ix, iy, iz;  // 1 / B_k (within one ulp)
   float nx, ny, nz;  // -A_k * (1 / B_k)
-  float ax, ay, az;  // |1 / B_k|
+  float ax, ay, az;  // (1 + sigma) / |B_k|, rounded up
 };
 
-constexpr float kBoxOriginLimit2 = 1023.0f;                // |A|^2 below this (|A| < 32)
 constexpr float kBoxMinDir = 9.313225746154785e-10f;       // 2^-30
-constexpr float kBoxMaxDir2 = 1099511627776.0f;            // 2^40
+constexpr float kBoxMaxNorm2 = 1099511627776.0f;           // 2^40
 
 RT_HD bool box_ray_in_range(V3 A, V3 B) {
   float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(B.x), __builtin_fabsf(B.y)), __builtin_fabsf(B.z));
-  return dot(A, A) < kBoxOriginLimit2 && lo >= kBoxMinDir && dot(B, B) < kBoxMaxDir2;
+  return dot(A, A) < kBoxMaxNorm2 && lo >= kBoxMinDir && dot(B, B) < kBoxMaxNorm2;
 }
 
 RT_HD float rt_rcp(float x) {
@@ -303,11 +312,14 @@ RT_HD float rt_rcp(float x) {
 #endif
 }
 
-RT_HD BoxRay make_box_ray(V3 A, V3 B) {
+// sigma0, sigma1: the scene's (rt_cluster.h).  The factor 1 + 2^-19 covers the roundings of this
+// function (|A|^2, sigma, the products) and the one-ulp reciprocal.
+RT_HD BoxRay make_box_ray(V3 A, V3 B, float sigma0, float sigma1) {
   BoxRay r;
   r.ix = rt_rcp(B.x); r.iy = rt_rcp(B.y); r.iz = rt_rcp(B.z);
   r.nx = -A.x * r.ix; r.ny = -A.y * r.iy; r.nz = -A.z * r.iz;
-  r.ax = __builtin_fabsf(r.ix); r.ay = __builtin_fabsf(r.iy); r.az = __builtin_fabsf(r.iz);
+  const float grow = (1.0f + rt_fma(sigma1, dot(A, A), sigma0)) * 1.0000019073486328f;   // (1 + sigma)(1 + 2^-19)
+  r.ax = __builtin_fabsf(r.ix) * grow; r.ay = __builtin_fabsf(r.iy) * grow; r.az = __builtin_fabsf(r.iz) * grow;
   return r;
 }
 

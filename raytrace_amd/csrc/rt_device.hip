@@ -74,6 +74,7 @@ struct DeviceScene {
   const uint32_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (byte 0, byte 1); dwords so
                                // that the wave-uniform read is a scalar load
   uint32_t n, n_pad;
+  float sigma0, sigma1;   // per-ray growth of the group boxes (rt_core.h, rt_cluster.h)
   uint32_t n_full;        // scan positions up to the last real sphere, rounded up to a round (16): what a
                           // scan without culling has to visit (the rest is padding)
 };
@@ -295,8 +296,8 @@ struct BoxRayP {
   f32x2 p0;  // {1/Bx, 1/By}
   f32x2 p1;  // {1/Bz, -Ax/Bx}
   f32x2 p2;  // {-Ay/By, -Az/Bz}
-  f32x2 p3;  // {|1/Bx|, |1/By|}
-  f32x2 p4;  // {|1/Bz|, unused}
+  f32x2 p3;  // {(1+sigma)/|Bx|, (1+sigma)/|By|}
+  f32x2 p4;  // {(1+sigma)/|Bz|, unused}
 };
 
 __device__ __forceinline__ BoxRayP pack_box_ray(const BoxRay &r) {
@@ -498,7 +499,7 @@ template <bool kBatched, bool kCull, bool kProfile = false>
 __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const ScanLds &lds, uint32_t tid, bool alive,
                                                   V3 A, V3 B, float tmin, float tmax, HitState &h) {
   const FilterRayP fr = pack_ray(alive ? make_filter_ray(A, B) : dead_ray());
-  const BoxRayP br = pack_box_ray(make_box_ray(A, B));
+  const BoxRayP br = pack_box_ray(make_box_ray(A, B, sc.sigma0, sc.sigma1));
   const float a = dot(B, B);
   // rays outside the range the group boxes were derived for scan every group
   const bool uncullable = kCull && alive && !box_ray_in_range(A, B);
@@ -1128,6 +1129,7 @@ struct rt_ctx {
   DevBuf<uint32_t> orig;
   DevBuf<uint32_t> round_real;
   uint32_t n = 0, n_pad = 0, n_full = 0;
+  float sigma0 = 0.0f, sigma1 = 0.0f;
   DevBuf<unsigned long long> counters;
   DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
   DevBuf<float4> rad;                // per-path radiance of one sample batch
@@ -1162,7 +1164,7 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->round_real.p, c->n, c->n_pad, c->n_full};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->round_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
 }
 
 size_t scan_lds_bytes(uint32_t entries) {
@@ -1502,6 +1504,8 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
   c->n_pad = n_pad;
+  c->sigma0 = L.sigma0;
+  c->sigma1 = L.sigma1;
   uint32_t last_real = 0;
   for (uint32_t p = 0; p < n_pad; ++p)
     if (L.order[p] != 0xffffffffu) last_real = p;

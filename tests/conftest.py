@@ -136,5 +136,4 @@ def leaving_rays(rng, spheres, n):
     B = tang * rng.uniform(0, 1, n)[:, None] + nrm * lean[:, None]
     B *= rng.choice([1e-6, 1e-4, 1e-2, 1, 1, 1e3], n)[:, None]
     B[rng.random(n) < 0.05, rng.integers(0, 3)] = 0.0
-    keep = np.linalg.norm(A, axis=1) < 31.0
-    return np.concatenate([A, B], axis=1).astype(np.float32)[keep]
+    return np.concatenate([A, B], axis=1).astype(np.float32)

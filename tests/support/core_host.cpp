@@ -91,7 +91,7 @@ uint64_t core_cull_check(const rt_sphere *s, size_t n, const float *rays, size_t
     V3 A = v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]);
     V3 B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
     if (!box_ray_in_range(A, B)) continue;   // the kernel scans every group for such rays
-    const BoxRay br = make_box_ray(A, B);
+    const BoxRay br = make_box_ray(A, B, L.sigma0, L.sigma1);
     const float a = dot(B, B);
     const double inv_a = 1.0 / (double)a;
     for (size_t g = 0; g < L.boxes.size(); g++) {

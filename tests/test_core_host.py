@@ -45,7 +45,8 @@ def test_group_culling_never_hides_a_hit(core, rt, builder):
     assert n_scan.value >= len(sc) and n_scan.value < len(sc) + 64 + len(sc) // 4
     rng = np.random.default_rng(8)
     rays = np.concatenate([random_rays(rng, 20000, sc), adversarial_rays(rng, sc, 20000), leaving_rays(rng, sc, 60000)])
-    rays[::5, :3] *= 2.5          # some origins beyond the culling limit too
+    rays[::5, :3] *= 2.5          # origins farther out: the boxes grow with the distance from the world origin
+    rays[3::50, :3] *= 40.0
     culled, groups = C.c_uint64(), C.c_uint64()
     core.core_cull_check.restype = C.c_uint64
     bad = core.core_cull_check(vp(sc), C.c_size_t(len(sc)), vp(rays), C.c_size_t(len(rays)), C.byref(culled), C.byref(groups))
