@@ -41,9 +41,14 @@ RT_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 RT_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // c/vec.c:37-39
 RT_HD float length(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
-// c/vec.c:41-46: reciprocal as a double divide narrowed to float
+// c/vec.c:41-46 forms the reciprocal as a double divide narrowed to float, (float)(1.0 / (double)len).
+// That is the correctly rounded float reciprocal: 1/len for a 24-bit len is at least 2^-49 (relative)
+// away from every midpoint of two floats, so rounding it to double first cannot move it across one
+// (checked for every float by the test suite).  A float divide is half the instructions.
+RT_HD float narrowed_double_reciprocal(float x) { return 1.0f / x; }
+
 RT_HD V3 normalize(V3 a) {
-  float k = (float)(1.0 / (double)length(a));
+  float k = narrowed_double_reciprocal(length(a));
   return k * a;
 }
 // c/vec.c:60-62
@@ -142,6 +147,14 @@ RT_HD void camera_ray(const Camera &c, float x, float y, Rng &g, V3 &A, V3 &B) {
 RT_HD void pixel_xy(uint32_t col, uint32_t up, uint32_t nx, uint32_t ny, Rng &g, float &x, float &y) {
   x = (float)((double)col + next_uniform(g)) / (float)nx;
   y = (float)((double)up + next_uniform(g)) / (float)ny;
+}
+
+// pixel_xy with the two divisions done by div_f32_by (below); inv_nx = 1.0 / (double)(float)nx, same for ny
+RT_HD float div_f32_by(float x, float k, double inv_k);
+RT_HD void pixel_xy_by(uint32_t col, uint32_t up, uint32_t nx, uint32_t ny, double inv_nx, double inv_ny, Rng &g, float &x,
+                       float &y) {
+  x = div_f32_by((float)((double)col + next_uniform(g)), (float)nx, inv_nx);
+  y = div_f32_by((float)((double)up + next_uniform(g)), (float)ny, inv_ny);
 }
 
 // ------------------------------------------------------- conservative filter
@@ -349,6 +362,15 @@ RT_HD double div_by_widened_float(double x, double da, double r) {
   return __builtin_fma(e0, r, q0);
 }
 
+// The float quotient x / k, given inv_k = 1.0 / (double)k (correctly rounded), for divisors that are
+// reused: a sphere's radius (c/main.c:229), the image size (c/main.c:465-466).  The double quotient
+// of two floats is at least 2^-49 (relative) away from every midpoint of two floats unless it is a
+// float itself, so narrowing the correctly rounded double quotient gives the correctly rounded float
+// quotient: five operations instead of the ten of a float divide.
+RT_HD float div_f32_by(float x, float k, double inv_k) {
+  return (float)div_by_widened_float((double)x, (double)k, inv_k);
+}
+
 // c/main.c:214-236 for one sphere.  r2 = radius*radius (a float product, as
 // the reference forms it); inv_a = 1.0 / (double)a.  On a hit inside
 // (tmin, tmax) returns true and t.
@@ -430,7 +452,7 @@ RT_HD V3 scatter_dielectric(V3 B, V3 n, float idx, Rng &g) {
     cosine = idx * bn / length(B);
   } else {
     outward = n;
-    ni_over_nt = (float)(1.0 / (double)idx);
+    ni_over_nt = narrowed_double_reciprocal(idx);   // (float)(1.0 / (double)idx), c/main.c:193
     cosine = -bn / length(B);
   }
   V3 bent;

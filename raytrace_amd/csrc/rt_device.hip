@@ -71,6 +71,7 @@ struct DeviceScene {
   const float4 *geom_o;   // {cx, cy, cz, radius}
   const float4 *mat_o;    // {albedo rgb, param}
   const int32_t *type_o;  // material type
+  const double *inv_r_o;  // 1.0 / (double)radius, for the divisions of c/main.c:229 (div_f32_by)
   const uint32_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (byte 0, byte 1); dwords so
                                // that the wave-uniform read is a scalar load
   uint32_t n, n_pad;
@@ -570,6 +571,7 @@ struct TraceArgs {
   uint32_t sample0;       // first sample of this batch
   uint32_t batch;         // SB: samples in this batch
   uint32_t total_items;   // tiles * SB * 64
+  double inv_nx, inv_ny;  // 1.0 / (double)(float)nx, ny (pixel_xy_by)
   DeviceScene sc;
   float4 *rad;            // [SB][rows*nx] {r, g, b, first-hit index bits}
   unsigned int *queue;    // next unclaimed item id
@@ -658,7 +660,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
           const float4 m4 = sc.mat_o[h.index];
           const int type = sc.type_o[h.index];
           p = A + h.closest * B;                              // c/structs.c:6-8
-          n = (p - v3(e.x, e.y, e.z)) / e.w;                  // c/main.c:229
+          const double inv_r = sc.inv_r_o[h.index];
+          const V3 pc = p - v3(e.x, e.y, e.z);
+          n = v3(div_f32_by(pc.x, e.w, inv_r), div_f32_by(pc.y, e.w, inv_r), div_f32_by(pc.z, e.w, inv_r));   // c/main.c:229
           if (type == RT_DIELECTRIC) {
             B = scatter_dielectric(B, n, m4.w, g);            // attenuation 1 (c/main.c:183)
             A = p;
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
           const uint32_t sample = args.sample0 + s_local;
           g.key = path_key(job.seed, grow * job.nx + col, sample);   // keyed by the global pixel
           g.k = 0;
-          pixel_xy(col, job.ny - 1u - grow, job.nx, job.ny, g, p.x, p.y);  // rows below = j-1 of c/main.c:466
+          pixel_xy_by(col, job.ny - 1u - grow, job.nx, job.ny, args.inv_nx, args.inv_ny, g, p.x, p.y);  // rows below = j-1 of c/main.c:466
           color = v3(1.0f, 1.0f, 1.0f);
           depth = 0;
           first_hit = -1;
@@ -1128,6 +1132,7 @@ struct rt_ctx {
   DevBuf<int32_t> type_o;
   DevBuf<uint32_t> orig;
   DevBuf<uint32_t> round_real;
+  DevBuf<double> inv_r_o;
   uint32_t n = 0, n_pad = 0, n_full = 0;
   float sigma0 = 0.0f, sigma1 = 0.0f;
   DevBuf<unsigned long long> counters;
@@ -1164,7 +1169,7 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->round_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->round_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
 }
 
 size_t scan_lds_bytes(uint32_t entries) {
@@ -1268,6 +1273,8 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
     const uint32_t sb = job->nsamples - s0 < batch ? job->nsamples - s0 : batch;
     t.sample0 = s0;
     t.batch = sb;
+    t.inv_nx = 1.0 / (double)(float)job->nx;
+    t.inv_ny = 1.0 / (double)(float)job->ny;
     t.total_items = tiles_x * tiles_y * sb * 64u;
     RT_HIP(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), c->stream));
     RT_HIP(hipEventRecord(pairs[used].first, c->stream));
@@ -1383,6 +1390,7 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->sboxes.release();
   c->orig.release();
   c->round_real.release();
+  c->inv_r_o.release();
   c->exact.release();
   c->geom_o.release();
   c->mat_o.release();
@@ -1450,6 +1458,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   if (n_pad > kMaxSpheres) return fail(RT_ERR_LIMIT, "too many spheres after padding");
   std::vector<float4> filter(n_pad), exact(n_pad), boxes(3 * (n_pad / 16)), sboxes(3 * (n_pad / 64)), geom_o(n), mat_o(n);
   std::vector<int32_t> type_o(n);
+  std::vector<double> inv_r_o(n);
   std::vector<uint32_t> round_real(n_pad / 16);
   std::vector<FilterSphere> fs(n_pad);
   for (size_t i = 0; i < n; ++i) {
@@ -1457,6 +1466,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     geom_o[i] = make_float4(s.center[0], s.center[1], s.center[2], s.radius);
     mat_o[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
     type_o[i] = s.type;
+    inv_r_o[i] = 1.0 / (double)s.radius;
   }
   for (uint32_t p = 0; p < n_pad; ++p) {
     const uint32_t i = L.order[p];
@@ -1490,7 +1500,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   int rc;
   if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(3 * (n_pad / 64))) || (rc = c->exact.reserve(n_pad)) ||
       (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
-      (rc = c->orig.reserve(n_pad)) || (rc = c->round_real.reserve(n_pad / 16)))
+      (rc = c->orig.reserve(n_pad)) || (rc = c->round_real.reserve(n_pad / 16)) || (rc = c->inv_r_o.reserve(n)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
@@ -1500,6 +1510,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->geom_o.p, geom_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->type_o.p, type_o.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->inv_r_o.p, inv_r_o.data(), n * sizeof(double), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;

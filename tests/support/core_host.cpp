@@ -6,6 +6,7 @@
 // flow.  The product library never runs this; there is no CPU render path.
 #include <cstddef>
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -257,6 +258,42 @@ uint64_t core_division_mismatches(uint64_t n, uint64_t seed) {
     }
     const double want = x / da, got = div_by_widened_float(x, da, r);
     if (memcmp(&want, &got, 8) != 0) bad++;
+  }
+  return bad;
+}
+
+// narrowed_double_reciprocal against the expression it replaces, for every float of one sign bit
+// (first .. last bit patterns); and div_f32_by against the float divide on random operands.
+uint64_t core_reciprocal_mismatches(uint32_t first, uint32_t last) {
+  uint64_t bad = 0;
+  for (uint64_t b = first; b <= last; b++) {
+    const uint32_t u = (uint32_t)b;
+    float x;
+    memcpy(&x, &u, 4);
+    if (!(x == x)) continue;
+    const float want = (float)(1.0 / (double)x), got = narrowed_double_reciprocal(x);
+    if (memcmp(&want, &got, 4) != 0) bad++;
+  }
+  return bad;
+}
+
+uint64_t core_float_division_mismatches(uint64_t n, uint64_t seed) {
+  uint64_t s = seed * 0x9e3779b97f4a7c15ull + 88172645463325252ull, bad = 0;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t kb = (uint32_t)rnd(), xb = (uint32_t)rnd();
+    if (i & 1) kb = (kb & 0xff800000u) | (0x7fffffu - (uint32_t)(rnd() & 7));
+    float k, x;
+    memcpy(&k, &kb, 4);
+    memcpy(&x, &xb, 4);
+    if (!(std::fabs(k) > 1e-30f && std::fabs(k) < 1e30f) || !(std::fabs(x) < 1e30f)) continue;
+    if (i % 5 == 0) {   // quotients next to a float midpoint
+      const float q = x / k, qn = std::nextafter(q, INFINITY);
+      x = (float)(((double)q + (double)qn) / 2 * (double)k);
+      if (!std::isfinite(x)) continue;   // (an infinite dividend gives NaN instead of infinity; a hit point is finite)
+    }
+    const float want = x / k, got = div_f32_by(x, k, 1.0 / (double)k);
+    if (memcmp(&want, &got, 4) != 0 && !(want == 0.0f && got == 0.0f)) bad++;
   }
   return bad;
 }

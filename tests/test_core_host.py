@@ -101,3 +101,15 @@ def test_reciprocal_division_is_correctly_rounded(core):
     the double quotient must be the same for every operand, the near-boundary ones included."""
     core.core_division_mismatches.restype = C.c_uint64
     assert core.core_division_mismatches(C.c_uint64(20_000_000), C.c_uint64(7)) == 0
+
+
+def test_float_reciprocal_equals_the_narrowed_double_reciprocal(core):
+    """normalize and the dielectric's 1/ref_idx use a float divide where c/vec.c:44 and c/main.c:193 narrow a
+    double reciprocal; the two agree for every float (all 2^31 magnitudes; the sign is symmetric)."""
+    core.core_reciprocal_mismatches.restype = C.c_uint64
+    assert core.core_reciprocal_mismatches(C.c_uint32(0), C.c_uint32(0x7F800000)) == 0
+
+
+def test_division_by_a_reused_float_divisor(core):
+    core.core_float_division_mismatches.restype = C.c_uint64
+    assert core.core_float_division_mismatches(C.c_uint64(20_000_000), C.c_uint64(3)) == 0
