@@ -49,6 +49,13 @@ using namespace rtcore;
 #else
 #define RT_ASM asm
 #endif
+// RT_EXP 31..39: the profiling build's "drain" column shows one stage of the shading phase instead
+// (31 rejection loop, 32 shading before it, 33 new paths, 34 shading after it)
+#define RT_STAGE_BEGIN(N) const unsigned long long stage_t0_##N = (RT_EXP == N && kProfile) ? tick() : 0ull
+#define RT_STAGE_END(N) \
+  do {                  \
+    if (RT_EXP == N && kProfile) c_drain += tick() - stage_t0_##N; \
+  } while (0)
 
 namespace {
 
@@ -544,9 +551,11 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   }
 }
 
-// global row of compact (tile-major) local row lr
-__device__ __forceinline__ uint32_t global_row(const rt_job &job, uint32_t lr) {
-  uint32_t t = lr / job.tile_rows;
+// global row of compact (tile-major) local row lr.  magic = ceil(2^32 / tile_rows) when the host found
+// the multiply-high quotient exact for every row of the job (rows * tile_rows < 2^32, tile_rows > 1),
+// else 0 and the division is done as such.
+__device__ __forceinline__ uint32_t global_row(const rt_job &job, uint32_t lr, uint32_t magic = 0u) {
+  uint32_t t = magic ? __umulhi(lr, magic) : lr / job.tile_rows;
   return job.row0 + t * job.tile_stride + (lr - t * job.tile_rows);
 }
 
@@ -572,6 +581,7 @@ struct TraceArgs {
   uint32_t batch;         // SB: samples in this batch
   uint32_t total_items;   // tiles * SB * 64
   double inv_nx, inv_ny;  // 1.0 / (double)(float)nx, ny (pixel_xy_by)
+  uint32_t tile_rows_magic;  // see global_row
   DeviceScene sc;
   float4 *rad;            // [SB][rows*nx] {r, g, b, first-hit index bits}
   unsigned int *queue;    // next unclaimed item id
@@ -600,6 +610,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
 
   // wave-uniform queue state
   uint32_t pool_next = 0, pool_end = 0;
+  // where the chunk in hand starts: its first (tile, sample) index and that index split into tile, sample
+  // and the tile into row and column of tiles -- one set of divisions per chunk instead of per path
+  uint32_t pool_ts0 = 0, pool_tile0 = 0, pool_s0 = 0, pool_ty0 = 0, pool_tx0 = 0;
   bool exhausted = false;
 
   bool alive = false;
@@ -648,6 +661,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
         n_tests += (unsigned long long)h.tests * live;
       }
       // ---- (2): shade, first part
+      RT_STAGE_BEGIN(32);
       if (alive) {
         if (kProfile) {
           n_own += h.own_groups;
@@ -683,8 +697,10 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
           alive = false;
         }
       }
+      RT_STAGE_END(32);
     }
     // ---- (3): hand new paths to the lanes without one
+    RT_STAGE_BEGIN(33);
     const unsigned long long idle_mask = __ballot(!alive);
     if (idle_mask != 0ull && !exhausted) {
       if (pool_next == pool_end) {
@@ -696,6 +712,11 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
         } else {
           pool_next = base;
           pool_end = min(base + kChunkItems, args.total_items);
+          pool_ts0 = base >> 6;
+          pool_tile0 = pool_ts0 / args.batch;
+          pool_s0 = pool_ts0 - pool_tile0 * args.batch;
+          pool_ty0 = pool_tile0 / args.tiles_x;
+          pool_tx0 = pool_tile0 - pool_ty0 * args.tiles_x;
         }
       }
       const uint32_t avail = pool_end - pool_next;
@@ -704,11 +725,21 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
       if (!alive && rank < avail) {
         const uint32_t id = pool_next + rank;
         const uint32_t l = id & 63u, ts = id >> 6;
-        const uint32_t tile = ts / args.batch, s_local = ts - tile * args.batch;
-        const uint32_t ty = tile / args.tiles_x, tx = tile - ty * args.tiles_x;
+        // (tile, sample) and (tile row, tile column) by stepping from the chunk's start: a chunk spans
+        // at most kChunkItems / 64 + 1 consecutive ts values, so the loops run once or not at all
+        // unless the batch or the image is only a few units wide
+        uint32_t s_local = pool_s0 + (ts - pool_ts0), tx = pool_tx0, ty = pool_ty0;
+        while (s_local >= args.batch) {
+          s_local -= args.batch;
+          tx++;
+        }
+        while (tx >= args.tiles_x) {
+          tx -= args.tiles_x;
+          ty++;
+        }
         const uint32_t col = tx * 8u + (l & 7u), lrow = ty * 8u + (l >> 3);
         if (col < job.nx && lrow < args.rows) {
-          const uint32_t grow = global_row(job, lrow);
+          const uint32_t grow = global_row(job, lrow, args.tile_rows_magic);
           const uint32_t sample = args.sample0 + s_local;
           g.key = path_key(job.seed, grow * job.nx + col, sample);   // keyed by the global pixel
           g.k = 0;
@@ -723,10 +754,14 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
       }
       pool_next += min((uint32_t)__popcll(idle_mask), avail);
     }
+    RT_STAGE_END(33);
     // ---- (4): the point in the unit ball
     V3 ball = v3(0, 0, 0);
+    RT_STAGE_BEGIN(31);
     if (pending != kNone) ball = unit_ball(g);
+    RT_STAGE_END(31);
     // ---- (5): shade, second part / camera ray
+    RT_STAGE_BEGIN(34);
     if (pending == kNewPath) {
       camera_ray_from(args.cam, p.x, p.y, ball, A, B);
     } else if (pending != kNone) {
@@ -750,11 +785,14 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
         alive = false;
       }
     }
+    RT_STAGE_END(34);
     n_paths += (unsigned long long)__popcll(__ballot(finished));
     if (kProfile) {
       unsigned long long c3 = tick();
       c_scan += c1 - c0;
+#if RT_EXP < 31 || RT_EXP > 39
       c_drain += c2 - c1;
+#endif
       c_shade += c3 - c2;
     }
     // ---- next trip, or the end: nothing to trace and nothing left to hand out
@@ -1275,6 +1313,9 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
     t.batch = sb;
     t.inv_nx = 1.0 / (double)(float)job->nx;
     t.inv_ny = 1.0 / (double)(float)job->ny;
+    t.tile_rows_magic = (job->tile_rows > 1 && (uint64_t)t.rows * job->tile_rows < (1ull << 32))
+                            ? (uint32_t)(((1ull << 32) + job->tile_rows - 1) / job->tile_rows)
+                            : 0u;
     t.total_items = tiles_x * tiles_y * sb * 64u;
     RT_HIP(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), c->stream));
     RT_HIP(hipEventRecord(pairs[used].first, c->stream));
