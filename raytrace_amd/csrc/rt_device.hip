@@ -79,6 +79,7 @@ struct DeviceScene {
   const float4 *mat_o;    // {albedo rgb, param}
   const int32_t *type_o;  // material type
   const double *inv_r_o;  // 1.0 / (double)radius, for the divisions of c/main.c:229 (div_f32_by)
+  const uint8_t *group_real;   // n_pad/8 entries: real (non-pad) spheres per group
   const uint32_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (byte 0, byte 1); dwords so
                                // that the wave-uniform read is a scalar load
   uint32_t n, n_pad;
@@ -108,7 +109,8 @@ struct HitState {
   float closest;    // smallest t (the query's tmax while there is no hit)
   int index;        // index of the sphere in the caller's list, -1 for none
   uint32_t cand;    // exact evaluations the wave performed (wave-uniform)
-  uint32_t tests;   // filter tests done per ray (bounds and spheres; wave-uniform)
+  uint32_t tests;   // filter tests every ray of the wave had done for it (box tests; without culling: all of them)
+  uint32_t lane_tests;   // sphere filter tests this lane evaluated, for whichever ray (culled scan)
   uint32_t own_groups;   // groups this lane's own ray needed (diagnostic: what a per-ray cull would scan)
   uint32_t wave_groups;  // groups the wave scanned
   unsigned long long drain_cycles;   // shader cycles in the closing drain (profiling builds only)
@@ -125,20 +127,26 @@ __device__ __forceinline__ FilterRay dead_ray() {
 }
 
 // LDS carve-up shared by every kernel that scans.  Per workgroup: the pair
-// image of the resident batch and its group boxes; per lane: its ray (so that
-// any lane of the wave can evaluate a sphere for it) and its best hit as one
-// 64-bit key {t bits, sphere index}; per wave: the list of (lane, sphere)
-// pairs that passed the filter and await exact evaluation.
-constexpr uint32_t kWaveListCap = 1024;             // entries per wave
-constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a chunk adds at most 64*kChunk: drain above this
+// image of the resident batch, its group boxes and the number of real spheres
+// of each group; per lane: its ray (so that any lane of the wave can evaluate a
+// sphere for it) and its best hit as one 64-bit key {t bits, sphere index}; per
+// wave: the list of (lane, group) pairs whose box test passed and await the
+// sphere filter, and the list of (lane, sphere) pairs that passed the filter
+// and await exact evaluation.
+constexpr uint32_t kWaveListCap = 768;              // (lane, sphere) entries per wave
+constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a pass adds at most 64*kChunk: drain above this
+constexpr uint32_t kPairListCap = 512;              // (lane, group) entries per wave, 16 bits each
+constexpr uint32_t kPairListFlush = kPairListCap - 2u * 64u;       // a round adds at most two groups for 64 lanes
 
 struct ScanLds {
   float4 *pairs;
   float4 *boxes;                 // 3 per round (16 spheres)
   float4 *sboxes;                // 3 per pair of super-groups (64 spheres)
-  float4 *rays;                  // 3 per lane: {A, a}, {B, tmin}, {1/a as a double, -, -}
+  float4 *rays;                  // 3 per lane: {A, a}, {B, -(B.B) of the filter}, {1/a as a double, A.B, naaa of the filter}
   unsigned long long *best;      // 1 per lane
   uint32_t *wlist;               // kWaveListCap per wave: (owner lane << 16) | scan position
+  uint16_t *plist;               // kPairListCap per wave: (group within the batch << 6) | owner lane
+  uint8_t *real8;                // per group of the batch: its real (non-pad) spheres
 };
 
 __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entries) {
@@ -149,6 +157,8 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
   l.rays = l.sboxes + 3u * (entries / 64u);
   l.best = reinterpret_cast<unsigned long long *>(l.rays + 3 * kBlockThreads);
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
+  l.plist = reinterpret_cast<uint16_t *>(l.wlist + (kBlockThreads / 64) * kWaveListCap);
+  l.real8 = reinterpret_cast<uint8_t *>(l.plist + (kBlockThreads / 64) * kPairListCap);
   return l;
 }
 
@@ -157,6 +167,7 @@ __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds
   for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[i] = sc.filter[base + i];
   for (uint32_t i = tid; i < 3u * (count / 16u); i += kBlockThreads) lds.boxes[i] = sc.boxes[3u * (base / 16u) + i];
   for (uint32_t i = tid; i < 3u * (count / 64u); i += kBlockThreads) lds.sboxes[i] = sc.sboxes[3u * (base / 64u) + i];
+  for (uint32_t i = tid; i < count / 8u; i += kBlockThreads) lds.real8[i] = sc.group_real[base / 8u + i];
 }
 
 // What a wave carries through one scan.
@@ -165,13 +176,18 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 // compiler turns such reads into scalar loads
 typedef const __attribute__((address_space(4))) uint32_t const_u32;
 
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
 struct WaveScan {
-  uint32_t wlist_off;            // LDS byte address of this wave's list (wave-uniform, held in a scalar register)
+  uint32_t wlist_off;            // LDS byte address of this wave's (lane, sphere) list (wave-uniform, in a scalar register)
+  uint32_t plist_off;            // the same for its (lane, group) list
   const float4 *rays;            // this wave's 64 rays (lane l at [3l] .. [3l+2])
   unsigned long long *best;      // this wave's 64 keys
-  uint32_t wcnt;                 // entries in the list (wave-uniform)
+  uint32_t wcnt;                 // entries in the (lane, sphere) list (wave-uniform)
+  uint32_t pcnt;                 // entries in the (lane, group) list (wave-uniform)
   uint32_t lane;
-  uint32_t lane16;               // lane << 16, the owner field of a list entry
+  uint32_t lane16;               // lane << 16, the owner field of a (lane, sphere) entry
+  float tmin;                    // of the query (wave-uniform)
 };
 
 // Exact evaluation (c/main.c:214-236) of the listed (lane, sphere) pairs, 64
@@ -194,7 +210,7 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
       const double inv_a = *reinterpret_cast<const double *>(&w.rays[3 * owner + 2]);
       const float4 ex = sc.exact[pos];
       float t;
-      if (exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, inv_a, ex.x, ex.y, ex.z, ex.w, rb.w, kFltMax, t)) {
+      if (exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, inv_a, ex.x, ex.y, ex.z, ex.w, w.tmin, kFltMax, t)) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | sc.orig[pos];
         atomicMin(&w.best[owner], key);
       }
@@ -394,6 +410,68 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
   }
 }
 
+// The sphere filter for the listed (lane, group) pairs, 64 pairs at a time whichever lanes they belong
+// to: a ray needs two or three of a scene's groups, the 64 rays of a wave together three times as many,
+// and filtering a group for the whole wave would spend two thirds of the lanes on rays that cannot touch
+// it.  Each lane takes one pair, reads the owner's ray from the wave's table and rebuilds its filter
+// coefficients (negations and doublings: exact), reads the group's eight spheres from the pair image
+// (neighbouring list entries mostly name the same group, so most of these reads are broadcasts) and
+// evaluates the same 32 packed FMAs as the full scan does, hence the same bits.  Spheres that pass go
+// to the (lane, sphere) list under the owner's name.
+__device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const float4 *lds_pairs, const uint8_t *lds_real8,
+                                                    uint32_t base, WaveScan &w, HitState &h) {
+  for (uint32_t e0 = 0; e0 < w.pcnt; e0 += 64u) {
+    if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);   // rare: the list usually lasts the whole scan
+    const uint32_t e = e0 + w.lane;
+    const bool valid = e < w.pcnt;
+    const uint32_t entry = valid ? (uint32_t)*(lds_u16 *)(uintptr_t)(w.plist_off + (e << 1)) : 0u;
+    const uint32_t owner = entry & 63u, grp = entry >> 6;
+    const float4 ra = w.rays[3 * owner], rb = w.rays[3 * owner + 1], rc = w.rays[3 * owner + 2];
+    FilterRayP f;
+    f.p0 = f32x2{-rb.x, -rb.y};
+    f.p1 = f32x2{-rb.z, rc.z};
+    f.p2 = f32x2{-2.0f * ra.x, -2.0f * ra.y};
+    f.p3 = f32x2{-2.0f * ra.z, rb.w};
+    f.p4 = f32x2{rc.w, 0.0f};
+    ChunkRegs r;
+    load_chunk(r, lds_pairs, grp * kChunk);
+    f32x2 d[kChunk / 2];
+    filter_four_pairs(f, r.q, d);
+#if RT_EXP == 12
+    {
+      f32x2 d2[kChunk / 2];
+      filter_four_pairs(f, r.q, d2);
+      asm volatile("" ::"v"(d2[0]), "v"(d2[1]), "v"(d2[2]), "v"(d2[3]));
+    }
+#endif
+    if (valid) h.lane_tests += lds_real8[grp];
+    // first word of this lane's entries: owner | scan position of the group's first sphere
+    const uint32_t word0 = (owner << 16) | (base + grp * kChunk);
+    const unsigned long long valid_mask = __ballot(valid);   // (a scalar AND per sphere instead of a vector select)
+    unsigned long long m[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) m[u] = __ballot(d[u >> 1][u & 1] > 0.0f) & valid_mask;
+    const unsigned long long any = ((m[0] | m[1]) | (m[2] | m[3])) | ((m[4] | m[5]) | (m[6] | m[7]));
+    if (any != 0ull) {
+      asm volatile("");  // (keeps the block a branch target; without it the nested ifs are merged)
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        if (m[u] != 0ull) {
+          asm volatile("");
+          const uint32_t rank =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+          uint32_t tail = w.wlist_off + (w.wcnt << 2);
+          asm("" : "+s"(tail));   // keep it one scalar operand
+          lds_u32 *dst = (lds_u32 *)(uintptr_t)(tail + (rank << 2));
+          if (d[u >> 1][u & 1] > 0.0f && valid) *dst = word0 + (uint32_t)u;
+          w.wcnt += (uint32_t)__popcll(m[u]);
+        }
+      }
+    }
+  }
+  w.pcnt = 0;
+}
+
 // Scan `count` spheres (a multiple of kDrainEvery = two groups) whose pair
 // image is in LDS.  The LDS image holds sphere PAIRS: 32 bytes {cx0,cx1,
 // cy0,cy1, cz0,cz1, K'0,K'1}, read as wave-wide broadcast ds_read_b128; one
@@ -403,14 +481,16 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
 // arithmetic in a second register set, so their latency is covered by the 32
 // packed FMAs of the chunk in hand rather than waited for.
 //
-// kCull = true: each round first tests the boxes of its two groups (one packed
-// evaluation, read one round ahead) and skips a group no lane's ray can touch.
-// `uncullable` lanes (rays outside the range the boxes are valid for) take
-// every group; lanes without a ray take none.
+// kCull = true: the boxes of the super-groups and, inside a super-group some
+// lane's ray can touch, of the groups are tested against every lane's ray; a
+// lane whose ray can touch a group puts (lane, group) on the wave's list, and
+// filter_listed_pairs does the rest.  `uncullable` lanes (rays outside the
+// range the boxes are valid for) list every group; lanes without a ray none.
 template <bool kCull>
-__device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *lds_pairs, const float4 *lds_boxes,
-                                           const float4 *lds_sboxes, uint32_t base, uint32_t count, const FilterRayP &fr, const BoxRayP &br,
-                                           bool alive, bool uncullable, WaveScan &w, HitState &h) {
+__device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
+                                           const FilterRayP &fr, const BoxRayP &br, bool alive, bool uncullable,
+                                           WaveScan &w, HitState &h) {
+  const float4 *lds_pairs = lds.pairs, *lds_boxes = lds.boxes, *lds_sboxes = lds.sboxes;
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
   if (!kCull) {
     ChunkRegs ra, rb;
@@ -428,7 +508,19 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
   }
   const unsigned long long all_mask = __ballot(uncullable), live_mask = __ballot(alive);
   uint32_t tests = 0;
-  // one round: the two boxes in q, then the groups some lane's ray can touch
+  // one group the box test (or nothing) lets some lanes through to: list (lane, group) for those lanes
+  auto list_group = [&](unsigned long long m, bool mine, uint32_t grp) {
+    if (m != 0ull) {
+      asm volatile("");
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      uint32_t tail = w.plist_off + (w.pcnt << 1), field = grp << 6;
+      asm("" : "+s"(tail), "+s"(field));   // keep each one scalar operand
+      lds_u16 *dst = (lds_u16 *)(uintptr_t)(tail + (rank << 1));
+      if (mine) *dst = (uint16_t)(field | w.lane);
+      w.pcnt += (uint32_t)__popcll(m);
+    }
+  };
+  // one round: the two boxes in q against every lane's ray
   auto round = [&](const float4 (&q)[3], uint32_t i0) {
     bool pass[2];
     box_pair(br, q, pass);
@@ -439,27 +531,14 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
       asm volatile("" ::"s"(__ballot(pass2[0])), "s"(__ballot(pass2[1])));
     }
 #endif
+    const bool mine0 = (pass[0] && alive) || uncullable, mine1 = (pass[1] && alive) || uncullable;
     const unsigned long long m0 = (__ballot(pass[0]) & live_mask) | all_mask, m1 = (__ballot(pass[1]) & live_mask) | all_mask;
-    const uint32_t real = ((const_u32 *)(uintptr_t)sc.round_real)[(base + i0) >> 4];
     tests += 2u;
-    h.own_groups += (pass[0] ? 1u : 0u) + (pass[1] ? 1u : 0u);
+    h.own_groups += (mine0 ? 1u : 0u) + (mine1 ? 1u : 0u);
     h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
-    if (m0 != 0ull) {
-      asm volatile("");
-      if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);   // rare: the list usually lasts the whole scan
-      ChunkRegs r;
-      load_chunk(r, lds_pairs, i0);
-      filter_chunk(r, base + i0, fr, w);
-      tests += real & 0xffu;
-    }
-    if (m1 != 0ull) {
-      asm volatile("");
-      if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);
-      ChunkRegs r;
-      load_chunk(r, lds_pairs, i0 + kChunk);
-      filter_chunk(r, base + i0 + kChunk, fr, w);
-      tests += real >> 8;
-    }
+    if (w.pcnt > kPairListFlush) filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);
+    list_group(m0, mine0, i0 >> 3);
+    list_group(m1, mine1, (i0 >> 3) + 1u);
   };
   // Super-groups first: the boxes of a pair of super-groups (64 spheres) in one packed evaluation, read
   // one pair ahead in a second register set; only a super-group some lane's ray can touch has its two
@@ -495,6 +574,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
     sq[1] = n1;
     sq[2] = n2;
   }
+  filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);   // (the pairs name groups of this batch)
   h.tests += tests;
 }
 
@@ -506,7 +586,8 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const float4 *
 template <bool kBatched, bool kCull, bool kProfile = false>
 __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const ScanLds &lds, uint32_t tid, bool alive,
                                                   V3 A, V3 B, float tmin, float tmax, HitState &h) {
-  const FilterRayP fr = pack_ray(alive ? make_filter_ray(A, B) : dead_ray());
+  const FilterRay f = alive ? make_filter_ray(A, B) : dead_ray();
+  const FilterRayP fr = pack_ray(f);   // (the culled scan rebuilds it from the wave's ray table instead)
   const BoxRayP br = pack_box_ray(make_box_ray(A, B, sc.sigma0, sc.sigma1));
   const float a = dot(B, B);
   // rays outside the range the group boxes were derived for scan every group
@@ -515,16 +596,21 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   WaveScan w;
   w.wlist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
       (int)(uint32_t)(uintptr_t)(lds_u32 *)(lds.wlist + (tid >> 6) * kWaveListCap));
+  w.plist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)(uint32_t)(uintptr_t)(lds_u16 *)(lds.plist + (tid >> 6) * kPairListCap));
   w.rays = lds.rays + 3 * wave_first;
   w.best = lds.best + wave_first;
   w.wcnt = 0;
+  w.pcnt = 0;
   w.lane = tid & 63u;
   w.lane16 = w.lane << 16;
+  w.tmin = tmin;
   // this lane's ray and "no hit yet" key where the other lanes of the wave can reach them; the
   // key {tmax bits, 0} can only be undercut by t < tmax
+  const double inv_a = 1.0 / (double)a;   // one division per ray, none per sphere
   lds.rays[3 * tid] = make_float4(A.x, A.y, A.z, a);
-  lds.rays[3 * tid + 1] = make_float4(B.x, B.y, B.z, tmin);
-  *reinterpret_cast<double *>(&lds.rays[3 * tid + 2]) = 1.0 / (double)a;   // one division per ray, none per sphere
+  lds.rays[3 * tid + 1] = make_float4(B.x, B.y, B.z, f.na);
+  lds.rays[3 * tid + 2] = make_float4(__int_as_float(__double2loint(inv_a)), __int_as_float(__double2hiint(inv_a)), f.ab, f.naaa);
   lds.best[tid] = (unsigned long long)__float_as_uint(tmax) << 32;
   if (kBatched) {
     for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
@@ -534,10 +620,10 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       __syncthreads();
       // (without culling the trailing padding is not visited)
       const uint32_t span = kCull ? count : (sc.n_full > base ? min(count, sc.n_full - base) : 0u);
-      scan_batch<kCull>(sc, lds.pairs, lds.boxes, lds.sboxes, base, span, fr, br, alive, uncullable, w, h);
+      scan_batch<kCull>(sc, lds, base, span, fr, br, alive, uncullable, w, h);
     }
   } else {
-    scan_batch<kCull>(sc, lds.pairs, lds.boxes, lds.sboxes, 0u, kCull ? sc.n_pad : sc.n_full, fr, br, alive, uncullable, w, h);
+    scan_batch<kCull>(sc, lds, 0u, kCull ? sc.n_pad : sc.n_full, fr, br, alive, uncullable, w, h);
   }
   if (!kCull) h.tests += sc.n;
   const unsigned long long d0 = kProfile ? tick() : 0ull;
@@ -622,6 +708,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
   Rng g{0u, 0u};
   // event counts of the wave, kept on the scalar unit (ballot popcounts and wave-uniform values)
   unsigned long long n_seg = 0, n_cand = 0, n_paths = 0, n_tests = 0;
+  uint32_t lane_tests = 0;                    // sphere tests this lane evaluated (culled scan), summed over the wave at the end
   unsigned long long n_own = 0, n_wave = 0;   // per lane, profiling builds only
   unsigned long long c_scan = 0, c_drain = 0, c_shade = 0, n_iter = 0, n_live = 0;
   const unsigned long long c_begin = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -648,7 +735,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
         n_iter++;
         n_live += (unsigned long long)__popcll(__ballot(alive));
       }
-      HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0ull};
+      HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u, 0ull};
       closest_hit_scene<kBatched, kCull, kProfile>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
       if (kProfile) {
         c2 = tick();
@@ -659,6 +746,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
         n_seg += live;
         n_cand += h.cand;
         n_tests += (unsigned long long)h.tests * live;
+        lane_tests += h.lane_tests;
       }
       // ---- (2): shade, first part
       RT_STAGE_BEGIN(32);
@@ -822,6 +910,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
     }
   }
   // event counts: one atomic per wave and counter
+  n_tests += wave_sum((unsigned long long)lane_tests);
   if (lane == 0 && args.counters) {
     atomicAdd(&args.counters[0], n_paths);
     atomicAdd(&args.counters[1], n_seg);
@@ -973,6 +1062,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
   int q[kWfSub];
   uint32_t pos[kWfSub];
   unsigned long long n_seg = 0, n_cand = 0, n_tests = 0;   // of the wave (wave-uniform)
+  uint32_t lane_tests = 0;
 #pragma unroll 1
   for (int sub = 0; sub < kWfSub; ++sub) {
     const uint32_t slot = blockIdx.x * kWfPerBlock + sub * kBlockThreads + tid;
@@ -990,13 +1080,14 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
       A = v3(o.x, o.y, o.z);
       B = v3(d.x, d.y, d.z);
     }
-    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u};
+    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u, 0ull};
     closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, args.job.tmin, kFltMax, h);
     {
       const uint32_t live = (uint32_t)__popcll(__ballot(alive));
       n_seg += live;
       n_cand += h.cand;
       n_tests += (unsigned long long)h.tests * live;
+      lane_tests += h.lane_tests;
     }
     if (alive) {
       // queue 0 = sky, 1 + material type otherwise
@@ -1016,6 +1107,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
       pool.qlist[(size_t)q[sub] * pool.slots + qbase[q[sub]] + pos[sub]] = slot;
     }
   }
+  n_tests += wave_sum((unsigned long long)lane_tests);
   if (lane == 0 && args.counters && n_seg) {
     atomicAdd(&args.counters[1], n_seg);
     atomicAdd(&args.counters[2], n_tests);
@@ -1101,7 +1193,7 @@ __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene 
     A = v3(rays[6 * r + 0], rays[6 * r + 1], rays[6 * r + 2]);
     B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
   }
-  HitState h{tmax, -1, 0u, 0u, 0u, 0u};
+  HitState h{tmax, -1, 0u, 0u, 0u, 0u, 0u, 0ull};
   closest_hit_scene<true, kCull>(sc, lds, tid, alive, A, B, tmin, tmax, h);
   if (alive) {
     index[r] = h.index;
@@ -1171,6 +1263,7 @@ struct rt_ctx {
   DevBuf<uint32_t> orig;
   DevBuf<uint32_t> round_real;
   DevBuf<double> inv_r_o;
+  DevBuf<uint8_t> group_real;
   uint32_t n = 0, n_pad = 0, n_full = 0;
   float sigma0 = 0.0f, sigma1 = 0.0f;
   DevBuf<unsigned long long> counters;
@@ -1207,13 +1300,14 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->round_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->group_real.p, c->round_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
 }
 
 size_t scan_lds_bytes(uint32_t entries) {
   return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u) * sizeof(float4) +  // pair image, boxes
          (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
-         (size_t)(kBlockThreads / 64) * kWaveListCap * sizeof(uint32_t);                    // wave lists
+         (size_t)(kBlockThreads / 64) * (kWaveListCap * sizeof(uint32_t) + kPairListCap * sizeof(uint16_t)) +  // wave lists
+         (size_t)((entries / 8u + 15u) & ~15u);                                              // real spheres per group
 }
 size_t trace_lds_bytes(uint32_t n_pad) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres); }
 
@@ -1432,6 +1526,7 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->orig.release();
   c->round_real.release();
   c->inv_r_o.release();
+  c->group_real.release();
   c->exact.release();
   c->geom_o.release();
   c->mat_o.release();
@@ -1541,7 +1636,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   int rc;
   if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(3 * (n_pad / 64))) || (rc = c->exact.reserve(n_pad)) ||
       (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
-      (rc = c->orig.reserve(n_pad)) || (rc = c->round_real.reserve(n_pad / 16)) || (rc = c->inv_r_o.reserve(n)))
+      (rc = c->orig.reserve(n_pad)) || (rc = c->round_real.reserve(n_pad / 16)) || (rc = c->inv_r_o.reserve(n)) || (rc = c->group_real.reserve(n_pad / 8)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
@@ -1552,6 +1647,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->type_o.p, type_o.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->inv_r_o.p, inv_r_o.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->group_real.p, L.real_in_group.data(), n_pad / 8, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
