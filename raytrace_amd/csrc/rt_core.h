@@ -405,9 +405,8 @@ RT_HD float schlick(float cosine, float ref_idx) {
   return (float)((double)r0 + (double)(1.0f - r0) * x5);
 }
 
-// c/main.c:146-158
-RT_HD bool refract(V3 u, V3 n, float ni_over_nt, V3 &out) {
-  V3 un = normalize(u);
+// c/main.c:146-158, given un = normalize(u)
+RT_HD bool refract_unit(V3 un, V3 n, float ni_over_nt, V3 &out) {
   float dt = dot(un, n);
   float D = (float)(1.0 - (double)(ni_over_nt * ni_over_nt * (1.0f - dt * dt)));
   if (D > 0.0f) {
@@ -417,6 +416,8 @@ RT_HD bool refract(V3 u, V3 n, float ni_over_nt, V3 &out) {
   }
   return false;
 }
+
+RT_HD bool refract(V3 u, V3 n, float ni_over_nt, V3 &out) { return refract_unit(normalize(u), n, ni_over_nt, out); }
 
 struct Material {
   int type;
@@ -434,33 +435,43 @@ RT_HD V3 scatter_matte(V3 p, V3 n, V3 ball) {
   return target - p;
 }
 
+// The sky, the metal and the dielectric case all start from normalize(B) (c/main.c:176, 148, 275) and
+// the dielectric also from |B| (c/main.c:189, 194); the *_unit forms take them as arguments so that a
+// caller whose lanes take different cases computes them once.
+//
 // metal, c/main.c:174-180: the new direction; false when the ray is absorbed (c/main.c:179)
-RT_HD bool scatter_metal(V3 B, V3 n, float fuzz, V3 ball, V3 &dir) {
-  V3 mirrored = reflect(normalize(B), n);
+RT_HD bool scatter_metal_unit(V3 unitB, V3 n, float fuzz, V3 ball, V3 &dir) {
+  V3 mirrored = reflect(unitB, n);
   dir = mirrored + fuzz * ball;
   return dot(dir, n) > 0.0f;
 }
 
+RT_HD bool scatter_metal(V3 B, V3 n, float fuzz, V3 ball, V3 &dir) { return scatter_metal_unit(normalize(B), n, fuzz, ball, dir); }
+
 // dielectric, c/main.c:181-206: the new direction
-RT_HD V3 scatter_dielectric(V3 B, V3 n, float idx, Rng &g) {
+RT_HD V3 scatter_dielectric_unit(V3 B, V3 unitB, float lenB, V3 n, float idx, Rng &g) {
   float bn = dot(B, n);
   V3 outward;
   float ni_over_nt, cosine;
   if (bn > 0.0f) {
     outward = -n;
     ni_over_nt = idx;
-    cosine = idx * bn / length(B);
+    cosine = idx * bn / lenB;
   } else {
     outward = n;
     ni_over_nt = narrowed_double_reciprocal(idx);   // (float)(1.0 / (double)idx), c/main.c:193
-    cosine = -bn / length(B);
+    cosine = -bn / lenB;
   }
   V3 bent;
   bool go_through = false;
-  if (refract(B, outward, ni_over_nt, bent)) {
+  if (refract_unit(unitB, outward, ni_over_nt, bent)) {
     go_through = next_uniform(g) >= (double)schlick(cosine, idx);
   }
   return go_through ? bent : reflect(B, n);
+}
+
+RT_HD V3 scatter_dielectric(V3 B, V3 n, float idx, Rng &g) {
+  return scatter_dielectric_unit(B, normalize(B), length(B), n, idx, g);
 }
 
 // c/main.c:163-211.  p, n: hit point and normal.  Returns false for an
@@ -482,14 +493,16 @@ RT_HD bool scatter(const Material &m, V3 A, V3 B, V3 p, V3 n, Rng &g, V3 &atten,
   return true;
 }
 
-// sky of c/main.c:274-278
-RT_HD V3 sky(V3 B) {
-  float t = (float)(0.5 * ((double)normalize(B).y + 1.0));
+// sky of c/main.c:274-278, given unit_y = normalize(B).y
+RT_HD V3 sky_unit(float unit_y) {
+  float t = (float)(0.5 * ((double)unit_y + 1.0));
   float k = (float)(1.0 - (double)t);
   V3 white = k * v3(1.0f, 1.0f, 1.0f);
   V3 blue = t * v3(0.75f, (float)0.95, 1.0f);
   return white + blue;
 }
+
+RT_HD V3 sky(V3 B) { return sky_unit(normalize(B).y); }
 
 // c/main.c:470-477: mean, square root, NaN scrub, truncation to 8 bits
 RT_HD void finish_pixel(V3 sum, uint32_t nsamples, V3 &mean, uint8_t rgb[3]) {

@@ -726,6 +726,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
     unsigned long long c0 = 0, c1 = 0, c2 = 0;
     int pending = kNone;
     V3 p = v3(0, 0, 0), n = v3(0, 0, 0), albedo = v3(0, 0, 0);   // (kNewPath: p.x, p.y hold the pixel's x, y)
+    V3 unitB = v3(0, 0, 1);                                        // normalize(B) of the ray just traced
     float fuzz = 0.0f;
     bool finished = false;
     if (kProfile) c0 = c1 = c2 = tick();
@@ -755,6 +756,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
           n_own += h.own_groups;
           n_wave += h.wave_groups;
         }
+        // the sky, the metal and the dielectric case each start from normalize(B): once, for all lanes
+        const float lenB = length(B);
+        unitB = narrowed_double_reciprocal(lenB) * B;               // c/vec.c:41-46
         bool done = false;
         if (depth == 0) first_hit = h.index;
         if (h.index >= 0) {
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
           const V3 pc = p - v3(e.x, e.y, e.z);
           n = v3(div_f32_by(pc.x, e.w, inv_r), div_f32_by(pc.y, e.w, inv_r), div_f32_by(pc.z, e.w, inv_r));   // c/main.c:229
           if (type == RT_DIELECTRIC) {
-            B = scatter_dielectric(B, n, m4.w, g);            // attenuation 1 (c/main.c:183)
+            B = scatter_dielectric_unit(B, unitB, lenB, n, m4.w, g);   // attenuation 1 (c/main.c:183)
             A = p;
             depth++;
             done = depth >= job.max_depth;                    // c/main.c:262, 282
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
             fuzz = m4.w;
           }
         } else {
-          color = color * sky(B);                             // c/main.c:274-279
+          color = color * sky_unit(unitB.y);                  // c/main.c:274-279
           done = true;
         }
         if (done) {
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
       } else {
         // c/main.c:270-272: after an absorbed ray the colour is 0 and stays 0 whatever the rest of the
         // reference's loop does with the ray, so the path ends
-        done = !scatter_metal(B, n, fuzz, ball, B);
+        done = !scatter_metal_unit(unitB, n, fuzz, ball, B);
         if (done) albedo = v3(0.0f, 0.0f, 0.0f);
       }
       A = p;
