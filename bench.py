@@ -75,9 +75,10 @@ def hbm_traffic(kernel_key):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             d = json.load(f)[kernel_key]
-        return (d["WRITE_SIZE_KB"] + 2.0 * d["FETCH_SIZE_KB"]) * 1024.0, d.get("source")
+        extra = {k: d.get(k) for k in ("VALUBusy", "VALUUtilization", "SQ_INSTS_VALU") if d.get(k) is not None}
+        return (d["WRITE_SIZE_KB"] + 2.0 * d["FETCH_SIZE_KB"]) * 1024.0, d.get("source"), extra
     except Exception:
-        return None, None
+        return None, None, {}
 
 
 def main():
@@ -202,8 +203,8 @@ def main():
         tests_per_launch = counters["tests"] / args.steps
         achieved = FLOP_PER_TEST * tests_per_launch / (k_ms * 1e-3) / 1e12
         # the counter passes were collected on this workload's 64-spp full frame; scaled to this rank's share
-        traffic, traffic_source = (hbm_traffic("full" if args.full_scan else "culled")
-                                   if args.kernel == "mega" and args.workload == "final1080" else (None, None))
+        traffic, traffic_source, counters_pmc = (hbm_traffic("full" if args.full_scan else "culled")
+                                                 if args.kernel == "mega" and args.workload == "final1080" else (None, None, {}))
         if traffic is not None:
             traffic *= spp_total / 64.0 * my_rows / ny
         out = {
@@ -235,6 +236,10 @@ def main():
                          "exact_evaluations_per_segment": counters["candidates"] / max(1, counters["segments"]),
                          "rank0_paths_per_launch": paths_per_step_rank},
         }
+        if counters_pmc:
+            # from the same committed counter passes: how busy the vector ALU was and how many of its lanes were active
+            out["roofline"]["pmc"] = {"valu_busy_pct": counters_pmc.get("VALUBusy"), "valu_thread_efficiency_pct": counters_pmc.get("VALUUtilization"),
+                                      "valu_wave_instructions_per_launch": counters_pmc.get("SQ_INSTS_VALU")}
         if linear is not None:
             out["linear_scan"] = linear
             # what the culled kernel delivers in units of the linear scan's work

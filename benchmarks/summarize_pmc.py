@@ -33,5 +33,7 @@ if len(sys.argv) > 2:
         cur = {}
     tk = next(v for k, v in out.items() if k.startswith("trace_kernel"))
     cur[sys.argv[2]] = {"FETCH_SIZE_KB": tk["FETCH_SIZE"], "WRITE_SIZE_KB": tk["WRITE_SIZE"],
+                        "VALUBusy": tk.get("VALUBusy"), "VALUUtilization": tk.get("VALUUtilization"),
+                        "SQ_INSTS_VALU": tk.get("SQ_INSTS_VALU"),
                         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py final1080, " + os.path.basename(root.rstrip("/"))}
     json.dump(cur, open(latest, "w"), indent=1, sort_keys=True)
