@@ -4,17 +4,19 @@
 // global queue; a lane whose path ends is handed the next one, so waves stay
 // full.  One trip of its loop is one bounce of every live lane:
 //   (1) closest hit.  The sphere list sits in LDS in scan order (rt_cluster.h)
-//       as 32-byte sphere pairs read as wave-wide broadcasts.  Per round of two
-//       groups of eight spheres the wave first tests the groups' boxes against
-//       every lane's half line and skips a group no lane can touch; a scanned
-//       group costs 32 packed FMAs (the eight-FMA conservative filter of
-//       rt_core.h on eight spheres).  (lane, sphere) pairs that pass go to a
-//       per-wave list in LDS; the list is drained 64 pairs at a time by
-//       whichever lanes are free, each pair through the reference's exact
-//       arithmetic (c/main.c:214-236) and an LDS 64-bit atomic min on
-//       {t, original index} -- the hit the reference's linear scan returns,
-//       because a sphere the filter rejects can never have D > 0 and the scan's
-//       result does not depend on its order except through that tie-break.
+//       as 32-byte sphere pairs.  Every lane's half line is tested against the
+//       boxes of the super-groups and, where some lane can touch one, of its
+//       groups of eight spheres; a lane whose ray can touch a group lists
+//       (lane, group).  The listed pairs are then filtered 64 at a time by
+//       whichever lanes are free: 32 packed FMAs per pair (the eight-FMA
+//       conservative filter of rt_core.h on eight spheres).  (lane, sphere)
+//       pairs that pass go to a second per-wave list, drained the same way,
+//       each pair through the reference's exact arithmetic (c/main.c:214-236)
+//       and an LDS 64-bit atomic min on {t, original index} -- the hit the
+//       reference's linear scan returns, because a sphere the filter rejects
+//       can never have D > 0 and the scan's result does not depend on its
+//       order except through that tie-break.  RT_FLAG_FULL_SCAN filters every
+//       sphere for every lane with wave-wide broadcast reads instead.
 //   (2)-(5) shading (c/main.c:163-211, 258-283) and new camera rays
 //       (c/structs.c:81-92) around ONE unit-ball rejection loop per trip.
 // resolve_kernel adds each pixel's samples in the reference's order
