@@ -106,11 +106,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # RT_BENCH_REHEARSAL=1: every rank on GPU 0 and the gather over gloo on host copies -- a way to walk the
+    # N > 1 control flow on a one-GPU box; its numbers mean nothing
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     scene_name, half_extent, nx, ny, spp, max_depth = WORKLOADS[args.workload]
     spp = args.spp or spp
@@ -142,7 +150,13 @@ def main():
         r.render_device(cam, job, tiles.data_ptr())
         if ev:
             ev[1].record(stream)
-        gather_frame(shards, tiles, rank, frame, gathered)     # the only communication: tiles -> rank 0
+        if rehearsal and world > 1:
+            stream.synchronize()
+            host = gather_frame(shards, tiles.cpu(), rank)
+            if rank == 0:
+                frame.copy_(host)
+        else:
+            gather_frame(shards, tiles, rank, frame, gathered)     # the only communication: tiles -> rank 0
 
     def fence():
         if world > 1:
@@ -168,7 +182,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     counters = r.counters()
