@@ -125,6 +125,38 @@ def test_render_equals_oracle(renderer, rt, oracle, scene, nx, ny, spp):
     assert c["paths"] >= nx * ny * spp
 
 
+@pytest.mark.parametrize("flags", [0, 2])
+def test_render_of_a_scene_that_streams_through_lds_in_batches(renderer, rt, oracle, flags):
+    """3,604 spheres (more than one 2,048-sphere batch): the kernel stages the list piecewise with the whole
+    workgroup in step; culled and full scan."""
+    sc = rt.random_scene(30)
+    assert len(sc) > 2048
+    renderer.upload(sc)
+    nx, ny, spp = 96, 54, 3
+    cam = rt.camera_default(nx, ny)
+    got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=5, flags=flags))
+    want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=5, host_threads=16)
+    assert_parity(got, want)
+
+
+def test_degenerate_spheres_and_rays_do_not_break_the_scan(renderer, rt, oracle):
+    """Zero and tiny radii, coincident centres, a sphere far from everything: such spheres go to the groups
+    every ray scans or stretch the boxes, and the picture must still be the oracle's."""
+    sc = rt.random_scene()[:120].copy()
+    sc["radius"][5] = 0.0
+    sc["radius"][6] = 1e-7
+    sc["radius"][7] = 1e-3
+    sc["center"][8] = sc["center"][9]
+    sc["center"][10] = (300.0, 40.0, -250.0)
+    sc["radius"][10] = 30.0
+    renderer.upload(sc)
+    nx, ny, spp = 120, 68, 4
+    cam = rt.camera_default(nx, ny)
+    got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=8))
+    want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=8, host_threads=16)
+    assert_parity(got, want)
+
+
 def test_ragged_sizes_depth_and_single_sample(renderer, rt, oracle):
     sc = rt.random_scene()
     renderer.upload(sc)
