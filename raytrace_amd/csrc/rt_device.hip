@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -660,21 +661,54 @@ __device__ __forceinline__ uint32_t global_row(const rt_job &job, uint32_t lr, u
 // order, which is the reference's summation order (c/main.c:462-469).
 constexpr uint32_t kChunkItems = 512;
 
-struct TraceArgs {
-  Camera cam;
+// image and queue geometry of a launch: what handing out new paths needs
+struct PathGeom {
   rt_job job;
   uint32_t rows;          // compact rows of the job
   uint32_t tiles_x;       // ceil(nx / 8)
   uint32_t sample0;       // first sample of this batch
   uint32_t batch;         // SB: samples in this batch
   uint32_t total_items;   // tiles * SB * 64
-  double inv_nx, inv_ny;  // 1.0 / (double)(float)nx, ny (pixel_xy_by)
   uint32_t tile_rows_magic;  // see global_row
+  double inv_nx, inv_ny;  // 1.0 / (double)(float)nx, ny (pixel_xy_by)
+};
+
+// the tables shading reads, in the caller's sphere order (a contiguous part of DeviceScene)
+struct ShadeTables {
+  const float4 *geom_o;
+  const float4 *mat_o;
+  const int32_t *type_o;
+  const double *inv_r_o;
+};
+static_assert(offsetof(DeviceScene, inv_r_o) - offsetof(DeviceScene, geom_o) == offsetof(ShadeTables, inv_r_o), "same layout");
+
+struct TraceArgs {
+  Camera cam;
+  PathGeom geo;
   DeviceScene sc;
   float4 *rad;            // [SB][rows*nx] {r, g, b, first-hit index bits}
   unsigned int *queue;    // next unclaimed item id
   unsigned long long *counters;
 };
+
+// A member of the kernel's argument struct, read from the kernel-argument segment at the point of use
+// through a pointer the compiler cannot see through (so the scalar loads stay there).  The struct has
+// some 80 words; held in scalar registers for the whole kernel they push other scalars out into
+// vector-register lanes, and every access to those costs a vector instruction.  Used for what the loop
+// touches once per trip outside the scan: the camera, the shading tables, the queue and image geometry.
+template <typename T>
+__device__ __forceinline__ T kernarg_now(size_t offset) {
+  static_assert(sizeof(T) % 4 == 0, "whole words");
+  const __attribute__((address_space(4))) unsigned char *ka =
+      (const __attribute__((address_space(4))) unsigned char *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const __attribute__((address_space(4))) uint32_t *src = (const __attribute__((address_space(4))) uint32_t *)(ka + offset);
+  T out;
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&out);
+#pragma unroll
+  for (int q = 0; q < (int)(sizeof(T) / 4); ++q) dst[q] = src[q];
+  return out;
+}
 
 // kProfile: also accumulate, per wave, the shader cycles spent in the scan, the
 // drain and the shading, and the number of live lanes per bounce iteration
@@ -684,12 +718,12 @@ template <bool kBatched, bool kCull, bool kProfile>
 __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DeviceScene &sc = args.sc;
-  const rt_job &job = args.job;
+  const rt_job &job = args.geo.job;
   const ScanLds lds = carve_lds(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
-  const uint32_t npix = args.rows * job.nx;
+  const uint32_t npix = args.geo.rows * job.nx;
 
   if (!kBatched) {
     stage_batch(sc, lds, 0u, sc.n_pad, tid);
@@ -764,11 +798,12 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
         bool done = false;
         if (depth == 0) first_hit = h.index;
         if (h.index >= 0) {
-          const float4 e = sc.geom_o[h.index];
-          const float4 m4 = sc.mat_o[h.index];
-          const int type = sc.type_o[h.index];
+          const ShadeTables tab = kernarg_now<ShadeTables>(offsetof(TraceArgs, sc) + offsetof(DeviceScene, geom_o));
+          const float4 e = tab.geom_o[h.index];
+          const float4 m4 = tab.mat_o[h.index];
+          const int type = tab.type_o[h.index];
           p = A + h.closest * B;                              // c/structs.c:6-8
-          const double inv_r = sc.inv_r_o[h.index];
+          const double inv_r = tab.inv_r_o[h.index];
           const V3 pc = p - v3(e.x, e.y, e.z);
           n = v3(div_f32_by(pc.x, e.w, inv_r), div_f32_by(pc.y, e.w, inv_r), div_f32_by(pc.z, e.w, inv_r));   // c/main.c:229
           if (type == RT_DIELECTRIC) {
@@ -786,7 +821,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
           done = true;
         }
         if (done) {
-          args.rad[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
+          kernarg_now<float4 *>(offsetof(TraceArgs, rad))[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
           finished = true;
           alive = false;
         }
@@ -797,20 +832,22 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
     RT_STAGE_BEGIN(33);
     const unsigned long long idle_mask = __ballot(!alive);
     if (idle_mask != 0ull && !exhausted) {
+      const PathGeom geo = kernarg_now<PathGeom>(offsetof(TraceArgs, geo));
+      const rt_job &jb = geo.job;
       if (pool_next == pool_end) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(args.queue, kChunkItems);
+        if (lane == 0) base = atomicAdd(kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)), kChunkItems);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= args.total_items) {
+        if (base >= geo.total_items) {
           exhausted = true;
         } else {
           pool_next = base;
-          pool_end = min(base + kChunkItems, args.total_items);
+          pool_end = min(base + kChunkItems, geo.total_items);
           pool_ts0 = base >> 6;
-          pool_tile0 = pool_ts0 / args.batch;
-          pool_s0 = pool_ts0 - pool_tile0 * args.batch;
-          pool_ty0 = pool_tile0 / args.tiles_x;
-          pool_tx0 = pool_tile0 - pool_ty0 * args.tiles_x;
+          pool_tile0 = pool_ts0 / geo.batch;
+          pool_s0 = pool_ts0 - pool_tile0 * geo.batch;
+          pool_ty0 = pool_tile0 / geo.tiles_x;
+          pool_tx0 = pool_tile0 - pool_ty0 * geo.tiles_x;
         }
       }
       const uint32_t avail = pool_end - pool_next;
@@ -823,25 +860,25 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
         // at most kChunkItems / 64 + 1 consecutive ts values, so the loops run once or not at all
         // unless the batch or the image is only a few units wide
         uint32_t s_local = pool_s0 + (ts - pool_ts0), tx = pool_tx0, ty = pool_ty0;
-        while (s_local >= args.batch) {
-          s_local -= args.batch;
+        while (s_local >= geo.batch) {
+          s_local -= geo.batch;
           tx++;
         }
-        while (tx >= args.tiles_x) {
-          tx -= args.tiles_x;
+        while (tx >= geo.tiles_x) {
+          tx -= geo.tiles_x;
           ty++;
         }
         const uint32_t col = tx * 8u + (l & 7u), lrow = ty * 8u + (l >> 3);
-        if (col < job.nx && lrow < args.rows) {
-          const uint32_t grow = global_row(job, lrow, args.tile_rows_magic);
-          const uint32_t sample = args.sample0 + s_local;
-          g.key = path_key(job.seed, grow * job.nx + col, sample);   // keyed by the global pixel
+        if (col < jb.nx && lrow < geo.rows) {
+          const uint32_t grow = global_row(jb, lrow, geo.tile_rows_magic);
+          const uint32_t sample = geo.sample0 + s_local;
+          g.key = path_key(jb.seed, grow * jb.nx + col, sample);   // keyed by the global pixel
           g.k = 0;
-          pixel_xy_by(col, job.ny - 1u - grow, job.nx, job.ny, args.inv_nx, args.inv_ny, g, p.x, p.y);  // rows below = j-1 of c/main.c:466
+          pixel_xy_by(col, jb.ny - 1u - grow, jb.nx, jb.ny, geo.inv_nx, geo.inv_ny, g, p.x, p.y);  // rows below = j-1 of c/main.c:466
           color = v3(1.0f, 1.0f, 1.0f);
           depth = 0;
           first_hit = -1;
-          out_index = s_local * npix + lrow * job.nx + col;
+          out_index = s_local * npix + lrow * jb.nx + col;
           alive = true;
           pending = kNewPath;
         }
@@ -857,7 +894,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
     // ---- (5): shade, second part / camera ray
     RT_STAGE_BEGIN(34);
     if (pending == kNewPath) {
-      camera_ray_from(args.cam, p.x, p.y, ball, A, B);
+      const Camera cam = kernarg_now<Camera>(offsetof(TraceArgs, cam));
+      camera_ray_from(cam, p.x, p.y, ball, A, B);
     } else if (pending != kNone) {
       bool done;
       if (pending == kMatte) {
@@ -874,7 +912,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
       depth++;
       done = done || depth >= job.max_depth;                  // c/main.c:262, 282
       if (done) {
-        args.rad[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
+        kernarg_now<float4 *>(offsetof(TraceArgs, rad))[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
         finished = true;
         alive = false;
       }
@@ -1012,7 +1050,7 @@ constexpr uint32_t kWfPerBlock = kWfSub * kBlockThreads;
 
 __global__ __launch_bounds__(kBlockThreads) void wf_generate(const TraceArgs args, const WfPool pool) {
   __shared__ uint32_t n_dead, base_id;
-  const rt_job &job = args.job;
+  const rt_job &job = args.geo.job;
   const uint32_t tid = threadIdx.x;
   if (tid == 0) n_dead = 0;
   __syncthreads();
@@ -1026,8 +1064,8 @@ __global__ __launch_bounds__(kBlockThreads) void wf_generate(const TraceArgs arg
   }
   __syncthreads();
   if (tid == 0) {
-    uint32_t b = args.total_items;
-    if (n_dead != 0 && pool.ctrl[kWfNext] < args.total_items) b = atomicAdd(&pool.ctrl[kWfNext], n_dead);
+    uint32_t b = args.geo.total_items;
+    if (n_dead != 0 && pool.ctrl[kWfNext] < args.geo.total_items) b = atomicAdd(&pool.ctrl[kWfNext], n_dead);
     base_id = b;
   }
   __syncthreads();
@@ -1036,14 +1074,14 @@ __global__ __launch_bounds__(kBlockThreads) void wf_generate(const TraceArgs arg
     if (!dead[sub]) continue;
     const uint32_t slot = blockIdx.x * kWfPerBlock + sub * kBlockThreads + tid;
     const uint32_t id = base_id + rank[sub];
-    if (id >= args.total_items) continue;
+    if (id >= args.geo.total_items) continue;
     const uint32_t l = id & 63u, ts = id >> 6;
-    const uint32_t tile = ts / args.batch, s_local = ts - tile * args.batch;
-    const uint32_t ty = tile / args.tiles_x, tx = tile - ty * args.tiles_x;
+    const uint32_t tile = ts / args.geo.batch, s_local = ts - tile * args.geo.batch;
+    const uint32_t ty = tile / args.geo.tiles_x, tx = tile - ty * args.geo.tiles_x;
     const uint32_t col = tx * 8u + (l & 7u), lrow = ty * 8u + (l >> 3);
-    if (col >= job.nx || lrow >= args.rows) continue;   // off-image id: the slot stays free
+    if (col >= job.nx || lrow >= args.geo.rows) continue;   // off-image id: the slot stays free
     const uint32_t grow = global_row(job, lrow);
-    Rng g{path_key(job.seed, grow * job.nx + col, args.sample0 + s_local), 0u};
+    Rng g{path_key(job.seed, grow * job.nx + col, args.geo.sample0 + s_local), 0u};
     float x, y;
     pixel_xy(col, job.ny - 1u - grow, job.nx, job.ny, g, x, y);
     V3 A, B;
@@ -1051,7 +1089,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_generate(const TraceArgs arg
     pool.org[slot] = make_float4(A.x, A.y, A.z, 0.0f);
     pool.dir[slot] = make_float4(B.x, B.y, B.z, __int_as_float(-1));
     pool.col[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(-1));
-    pool.misc[slot] = make_uint4(g.key, g.k, 0u, s_local * (args.rows * job.nx) + lrow * job.nx + col);
+    pool.misc[slot] = make_uint4(g.key, g.k, 0u, s_local * (args.geo.rows * job.nx) + lrow * job.nx + col);
   }
 }
 
@@ -1087,7 +1125,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
       B = v3(d.x, d.y, d.z);
     }
     HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u, 0ull};
-    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, args.job.tmin, kFltMax, h);
+    closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, args.geo.job.tmin, kFltMax, h);
     {
       const uint32_t live = (uint32_t)__popcll(__ballot(alive));
       n_seg += live;
@@ -1154,7 +1192,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_shade(const TraceArgs args, 
         color = atten * color;
         mi.y = g.k;
         mi.z += 1u;
-        finished = mi.z >= args.job.max_depth;
+        finished = mi.z >= args.geo.job.max_depth;
         if (!finished) {
           pool.org[slot] = make_float4(nA.x, nA.y, nA.z, 0.0f);
           pool.dir[slot] = make_float4(nB.x, nB.y, nB.z, __int_as_float(-1));
@@ -1343,11 +1381,11 @@ int run_wavefront_batch(rt_ctx *c, const TraceArgs &t, uint32_t valid_paths, boo
   RT_HIP(hipMemsetAsync(pool.misc, 0xff, (size_t)slots * sizeof(uint4), c->stream));
   RT_HIP(hipMemsetAsync(pool.ctrl, 0, kWfCtrlWords * sizeof(uint32_t), c->stream));
   const dim3 grid((slots + kWfPerBlock - 1) / kWfPerBlock), block(kBlockThreads);
-  const uint32_t min_rounds = (t.total_items + slots - 1) / slots;
+  const uint32_t min_rounds = (t.geo.total_items + slots - 1) / slots;
   for (uint32_t round = 0;; ++round) {
     RT_HIP(hipMemsetAsync(pool.ctrl + kWfQueue, 0, 4 * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(wf_generate, grid, block, 0, c->stream, t, pool);
-    const bool cull = (t.job.flags & RT_FLAG_FULL_SCAN) == 0;
+    const bool cull = (t.geo.job.flags & RT_FLAG_FULL_SCAN) == 0;
     if (batched && cull) hipLaunchKernelGGL((wf_intersect<true, true>), grid, block, lds, c->stream, t, pool);
     if (batched && !cull) hipLaunchKernelGGL((wf_intersect<true, false>), grid, block, lds, c->stream, t, pool);
     if (!batched && cull) hipLaunchKernelGGL((wf_intersect<false, true>), grid, block, lds, c->stream, t, pool);
@@ -1362,7 +1400,7 @@ int run_wavefront_batch(rt_ctx *c, const TraceArgs &t, uint32_t valid_paths, boo
       RT_HIP(hipMemcpyAsync(&finished, pool.ctrl + kWfFinished, sizeof finished, hipMemcpyDeviceToHost, c->stream));
       RT_HIP(hipStreamSynchronize(c->stream));
       if (finished >= valid_paths) break;
-      if (round > min_rounds + 4u * t.job.max_depth + 64u) return fail(RT_ERR_HIP, "wavefront variant did not drain");
+      if (round > min_rounds + 4u * t.geo.job.max_depth + 64u) return fail(RT_ERR_HIP, "wavefront variant did not drain");
     }
   }
   return RT_OK;
@@ -1384,9 +1422,9 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
 
   TraceArgs t;
   std::memcpy(&t.cam, cam, sizeof t.cam);
-  t.job = *job;
-  t.rows = rows;
-  t.tiles_x = tiles_x;
+  t.geo.job = *job;
+  t.geo.rows = rows;
+  t.geo.tiles_x = tiles_x;
   t.sc = scene_view(c);
   t.rad = c->rad.p;
   t.queue = c->queue.p;
@@ -1409,14 +1447,14 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
       pairs.emplace_back(e0, e1);
     }
     const uint32_t sb = job->nsamples - s0 < batch ? job->nsamples - s0 : batch;
-    t.sample0 = s0;
-    t.batch = sb;
-    t.inv_nx = 1.0 / (double)(float)job->nx;
-    t.inv_ny = 1.0 / (double)(float)job->ny;
-    t.tile_rows_magic = (job->tile_rows > 1 && (uint64_t)t.rows * job->tile_rows < (1ull << 32))
+    t.geo.sample0 = s0;
+    t.geo.batch = sb;
+    t.geo.inv_nx = 1.0 / (double)(float)job->nx;
+    t.geo.inv_ny = 1.0 / (double)(float)job->ny;
+    t.geo.tile_rows_magic = (job->tile_rows > 1 && (uint64_t)t.geo.rows * job->tile_rows < (1ull << 32))
                             ? (uint32_t)(((1ull << 32) + job->tile_rows - 1) / job->tile_rows)
                             : 0u;
-    t.total_items = tiles_x * tiles_y * sb * 64u;
+    t.geo.total_items = tiles_x * tiles_y * sb * 64u;
     RT_HIP(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), c->stream));
     RT_HIP(hipEventRecord(pairs[used].first, c->stream));
     if (job->kernel == RT_KERNEL_WAVEFRONT) {
