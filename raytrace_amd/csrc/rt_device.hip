@@ -543,39 +543,46 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     list_group(m0, mine0, i0 >> 3);
     list_group(m1, mine1, (i0 >> 3) + 1u);
   };
-  // Super-groups first: the boxes of a pair of super-groups (64 spheres) in one packed evaluation, read
-  // one pair ahead in a second register set; only a super-group some lane's ray can touch has its two
-  // rounds (four group boxes) looked at.
-  auto super_pair = [&](const float4 (&sq)[3], uint32_t i0) {
-    bool spass[2];
-    box_pair(br, sq, spass);
-    const unsigned long long s0 = (__ballot(spass[0]) & live_mask) | all_mask, s1 = (__ballot(spass[1]) & live_mask) | all_mask;
-    tests += 2u;
-#pragma unroll 1
-    for (uint32_t k = 0; k < 2u; ++k) {
-      if ((k ? s1 : s0) != 0ull) {
-        asm volatile("");
-        const uint32_t j0 = i0 + 2u * kDrainEvery * k;
-        const uint32_t ib = 3u * (j0 >> 4);
-#pragma unroll 1
-        for (uint32_t r = 0; r < 2u; ++r) {
-          const float4 q[3] = {lds_boxes[ib + 3u * r], lds_boxes[ib + 3u * r + 1], lds_boxes[ib + 3u * r + 2]};
-          round(q, j0 + kDrainEvery * r);
-        }
-      }
-    }
-  };
+  // Super-groups first, all of them in one tight loop (the boxes of a pair of super-groups, 64 spheres,
+  // in one packed evaluation; two pairs per trip so that the reads of one overlap the arithmetic of the
+  // other and no register is copied): a bit per super-group some lane's ray can touch.  A batch has at
+  // most 2048 / 32 = 64 super-groups.
   constexpr uint32_t kPairSpan = 4u * kDrainEvery;   // spheres per pair of super-groups
-  float4 sq[3] = {lds_sboxes[0], lds_sboxes[1], lds_sboxes[2]};
+  unsigned long long touched = 0ull;
+  {
+    auto test_pair = [&](const float4 (&sq)[3], uint32_t pair_index) {
+      bool spass[2];
+      box_pair(br, sq, spass);
+      const unsigned long long s0 = (__ballot(spass[0]) & live_mask) | all_mask, s1 = (__ballot(spass[1]) & live_mask) | all_mask;
+      touched |= (unsigned long long)((s0 != 0ull ? 1u : 0u) | (s1 != 0ull ? 2u : 0u)) << (2u * pair_index);
+    };
+    const uint32_t n_pairs = count / kPairSpan;
+    float4 sa[3] = {lds_sboxes[0], lds_sboxes[1], lds_sboxes[2]}, sb[3];
+    for (uint32_t pi = 0; pi < n_pairs; pi += 2u) {
+      const uint32_t ib = 3u * (pi + 1u < n_pairs ? pi + 1u : 0u);   // (a read past the end is redirected and not used)
+      sb[0] = lds_sboxes[ib];
+      sb[1] = lds_sboxes[ib + 1];
+      sb[2] = lds_sboxes[ib + 2];
+      test_pair(sa, pi);
+      const uint32_t ia = 3u * (pi + 2u < n_pairs ? pi + 2u : 0u);
+      sa[0] = lds_sboxes[ia];
+      sa[1] = lds_sboxes[ia + 1];
+      sa[2] = lds_sboxes[ia + 2];
+      if (pi + 1u < n_pairs) test_pair(sb, pi + 1u);
+    }
+    tests += 2u * n_pairs;
+  }
+  // then the two rounds (four group boxes) of every super-group that was touched
+  while (touched != 0ull) {
+    const uint32_t sg = (uint32_t)__builtin_ctzll(touched);
+    touched &= touched - 1ull;
+    const uint32_t j0 = sg * (2u * kDrainEvery);
+    const uint32_t ib = 3u * (j0 >> 4);
 #pragma unroll 1
-  for (uint32_t i0 = 0; i0 < count; i0 += kPairSpan) {
-    // the next pair's boxes are read before this pair is worked on (the read past the end is redirected)
-    const uint32_t in = 3u * ((i0 + kPairSpan < count ? i0 + kPairSpan : 0u) >> 6);
-    const float4 n0 = lds_sboxes[in], n1 = lds_sboxes[in + 1], n2 = lds_sboxes[in + 2];
-    super_pair(sq, i0);
-    sq[0] = n0;
-    sq[1] = n1;
-    sq[2] = n2;
+    for (uint32_t r = 0; r < 2u; ++r) {
+      const float4 q[3] = {lds_boxes[ib + 3u * r], lds_boxes[ib + 3u * r + 1], lds_boxes[ib + 3u * r + 2]};
+      round(q, j0 + kDrainEvery * r);
+    }
   }
   filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);   // (the pairs name groups of this batch)
   h.tests += tests;
