@@ -2,7 +2,7 @@
  * main.c -- command-line renderer: the reference's CLI (c/main.c:32-138) in
  * front of the GPU path.  Same options with the same meaning and messages
  * where they still apply:
- *     -o <file>.ppm | -     output file; '-' writes the PPM to stdout
+ *     -o <file>.<ppm|png> | -   output file; '-' writes the PPM to stdout
  *     -n <samples>          samples per pixel (default 10, c/main.c:61)
  *     -t <devices>          number of GPUs to shard over (the reference's
  *                           thread count, c/main.c:62; default 1)
@@ -27,7 +27,7 @@ static const char *argv0;
 static void usage(void) {
   fprintf(stderr,
           "Usage: %s [-n <number of samples>] [-t <number of GPUs>] [-x <width>] [-y <height>]\n"
-          "          [-s small|final|dense|glass|trivial] [-d <max depth>] [-S <seed>] -o <output file>.ppm\n"
+          "          [-s small|final|dense|glass|trivial] [-d <max depth>] [-S <seed>] -o <output file>.<ppm/png>\n"
           "\n"
           "If <output file> is '-' then a ppm image is written on stdout.\n"
           "\n"
@@ -53,6 +53,7 @@ static long positive(const char *what, const char *arg) {
 int main(int argc, char **argv) {
   argv0 = argv[0];
   FILE *fp = NULL;
+  int write_png = 0;
   rth_render_opts o;
   memset(&o, 0, sizeof o);
   o.nx = 600; o.ny = 300;          /* c/main.c:486 */
@@ -68,10 +69,12 @@ int main(int argc, char **argv) {
       if (strcmp(optarg, "-") == 0) { fp = stdout; break; }
       const char *ext = strrchr(optarg, '.');
       if (ext == NULL) {
-        fprintf(stderr, "missing file name extension, support ppm\n");
+        fprintf(stderr, "missing file name extension, support ppm/png\n");   /* c/main.c:80-83 */
         usage();
+      } else if (strcasecmp(ext, ".png") == 0) {
+        write_png = 1;
       } else if (strcasecmp(ext, ".ppm") != 0) {
-        fprintf(stderr, "unsupported file extension: %s (only support ppm)\n", ext);
+        fprintf(stderr, "unsupported file extension: %s (only support ppm/png)\n", ext);
         usage();
       }
       fp = fopen(optarg, "wb");
@@ -113,7 +116,10 @@ int main(int argc, char **argv) {
   double paths = (double)o.nx * o.ny * o.nsamples;
   fprintf(stderr, "raytracing took %.3f seconds (%zu spheres, %ux%u, %u spp, %d GPU(s); kernels %.3f ms, %.3g paths/s)\n",
           wall, n, o.nx, o.ny, o.nsamples, o.n_devices, kernel_ms, kernel_ms > 0 ? paths / (kernel_ms * 1e-3) : 0.0);
-  if (rth_write_ppm(fp, img, o.nx, o.ny) != RT_OK) { perror("could not write image"); return 1; }
+  if ((write_png ? rth_write_png(fp, img, o.nx, o.ny) : rth_write_ppm(fp, img, o.nx, o.ny)) != RT_OK) {
+    perror("could not write image");
+    return 1;
+  }
   if (fp != stdout && 0 != fclose(fp)) { perror("could not close output file"); exit(1); }   /* c/main.c:132-135 */
   free(img);
   free(spheres);

@@ -46,6 +46,8 @@ int rth_scene_build(int which, rt_sphere **out, size_t *n);
 
 /* ppm_write, c/main.c:410-415 */
 int rth_write_ppm(FILE *fp, const uint8_t *rgb8, size_t w, size_t h);
+/* c/main.c:427-433: 8-bit RGB PNG (stored, i.e. uncompressed, deflate blocks) */
+int rth_write_png(FILE *fp, const uint8_t *rgb8, size_t w, size_t h);
 
 /* raytrace(), c/main.c:485-548, with GPUs in place of threads: row tiles of
  * tile_rows rows are dealt round-robin over n_devices contexts (one host

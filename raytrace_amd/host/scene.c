@@ -194,3 +194,74 @@ int rth_write_ppm(FILE *fp, const uint8_t *rgb8, size_t w, size_t h) {
   if (w != 0 && h != 0 && fwrite(rgb8, 3 * w * h, 1, fp) != 1) return RT_ERR_ARG;
   return RT_OK;
 }
+
+/* ---- PNG (c/main.c:427-433 writes one through a third-party encoder; this is a writer of its own:
+ * 8-bit RGB, filter 0 on every row, the pixel stream in stored deflate blocks -- valid, uncompressed) ---- */
+
+static uint32_t crc_table[256];
+static int crc_ready = 0;
+
+static uint32_t crc32_update(uint32_t c, const uint8_t *p, size_t n) {
+  if (!crc_ready) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t r = i;
+      for (int k = 0; k < 8; k++) r = (r & 1u) ? 0xedb88320u ^ (r >> 1) : r >> 1;
+      crc_table[i] = r;
+    }
+    crc_ready = 1;
+  }
+  for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+  return c;
+}
+
+static void be32(uint8_t *o, uint32_t v) { o[0] = (uint8_t)(v >> 24); o[1] = (uint8_t)(v >> 16); o[2] = (uint8_t)(v >> 8); o[3] = (uint8_t)v; }
+
+static int png_chunk(FILE *fp, const char type[4], const uint8_t *data, size_t n) {
+  uint8_t head[8], tail[4];
+  be32(head, (uint32_t)n);
+  memcpy(head + 4, type, 4);
+  uint32_t c = crc32_update(0xffffffffu, head + 4, 4);
+  c = crc32_update(c, data, n) ^ 0xffffffffu;
+  be32(tail, c);
+  return fwrite(head, 8, 1, fp) == 1 && (n == 0 || fwrite(data, n, 1, fp) == 1) && fwrite(tail, 4, 1, fp) == 1;
+}
+
+int rth_write_png(FILE *fp, const uint8_t *rgb8, size_t w, size_t h) {
+  if (!fp || !rgb8 || w == 0 || h == 0 || w > 0x7fffffffu || h > 0x7fffffffu) return RT_ERR_ARG;
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  uint8_t ihdr[13];
+  be32(ihdr, (uint32_t)w);
+  be32(ihdr + 4, (uint32_t)h);
+  ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;   /* 8 bits, RGB, deflate, no filter method, no interlace */
+  const size_t row = 3 * w + 1, raw = row * h;
+  const size_t blocks = (raw + 65534) / 65535;
+  const size_t zlen = 2 + raw + 5 * blocks + 4;
+  uint8_t *z = (uint8_t *)malloc(zlen);
+  if (!z) return RT_ERR_NOMEM;
+  size_t o = 0;
+  z[o++] = 0x78; z[o++] = 0x01;                       /* zlib header: deflate, 32 KiB window, no preset dictionary */
+  uint32_t a = 1, b = 0;                              /* Adler-32 of the raw stream */
+  size_t in_block = 0, left = raw;
+  for (size_t y = 0; y < h; y++) {
+    for (size_t k = 0; k < row; k++) {
+      if (in_block == 0) {                            /* a stored block: final flag, LEN, ~LEN */
+        size_t len = left < 65535 ? left : 65535;
+        z[o++] = (uint8_t)(left <= 65535);
+        z[o++] = (uint8_t)len; z[o++] = (uint8_t)(len >> 8);
+        z[o++] = (uint8_t)~len; z[o++] = (uint8_t)(~len >> 8);
+        in_block = len;
+      }
+      uint8_t v = k == 0 ? 0 : rgb8[y * 3 * w + (k - 1)];   /* first byte of a row: filter type 0 */
+      z[o++] = v;
+      a = (a + v) % 65521u;
+      b = (b + a) % 65521u;
+      in_block--;
+      left--;
+    }
+  }
+  be32(z + o, (b << 16) | a);
+  o += 4;
+  int ok = fwrite(sig, 8, 1, fp) == 1 && png_chunk(fp, "IHDR", ihdr, 13) && png_chunk(fp, "IDAT", z, o) && png_chunk(fp, "IEND", NULL, 0);
+  free(z);
+  return ok ? RT_OK : RT_ERR_ARG;
+}

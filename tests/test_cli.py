@@ -44,3 +44,16 @@ def test_cli_renders_the_same_bytes_as_the_library(tmp_path, renderer, rt):
     assert blob[len(b"P6\n200 100 255\n"):] == want.tobytes()
     p2 = run("-s", "final", "-x", "200", "-y", "100", "-n", "4", "-o", "-")           # '-' = stdout, c/main.c:68-70
     assert p2.returncode == 0 and hashlib.sha256(p2.stdout).digest() == hashlib.sha256(blob).digest()
+    # the same picture as PNG (c/main.c:78-79 picks the writer by extension)
+    import struct
+    import zlib
+    png = tmp_path / "o.png"
+    p3 = run("-s", "final", "-x", "200", "-y", "100", "-n", "4", "-o", str(png))
+    assert p3.returncode == 0, p3.stderr
+    raw = png.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    (n,) = struct.unpack(">I", raw[33:37])
+    assert raw[37:41] == b"IDAT"
+    rows = np.frombuffer(zlib.decompress(raw[41:41 + n]), np.uint8).reshape(100, 601)
+    assert np.array_equal(rows[:, 1:].reshape(100, 200, 3), want)
+

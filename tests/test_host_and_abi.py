@@ -67,3 +67,38 @@ def test_bad_arguments_are_errors_not_aborts(rt):
     assert d.rt_scene_upload(None, None, 0) == 1
     assert d.rt_render_host(None, None, None, None, None, None, None) == 1
     assert d.rt_ctx_destroy(None) == 0
+
+
+def test_png_writer_produces_a_decodable_image(rt, tmp_path):
+    """rth_write_png (c/main.c:427-433 writes PNG through a third-party encoder; this one is the build's own):
+    signature, IHDR, stored-deflate IDAT that zlib inflates to the filter-0 rows, chunk CRCs."""
+    import ctypes as C
+    import struct
+    import zlib
+    rng = np.random.default_rng(2)
+    for w, h in ((1, 1), (37, 5), (300, 200)):   # the last one needs more than one 65535-byte stored block
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        path = str(tmp_path / f"t_{w}x{h}.png")
+        libc = C.CDLL(None)
+        libc.fopen.restype = C.c_void_p
+        libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        fp = libc.fopen(path.encode(), b"wb")
+        assert fp
+        assert rt._native.host.rth_write_png(fp, img.ctypes.data, w, h) == 0
+        libc.fclose(fp)
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, chunks = 8, []
+        while pos < len(raw):
+            (n,) = struct.unpack(">I", raw[pos:pos + 4])
+            kind, body = raw[pos + 4:pos + 8], raw[pos + 8:pos + 8 + n]
+            (crc,) = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+            assert crc == zlib.crc32(kind + body) & 0xFFFFFFFF
+            chunks.append((kind, body))
+            pos += 12 + n
+        assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+        rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 3 * w + 1)
+        assert (rows[:, 0] == 0).all()
+        assert np.array_equal(rows[:, 1:].reshape(h, w, 3), img)
