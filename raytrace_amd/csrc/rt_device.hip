@@ -83,8 +83,6 @@ struct DeviceScene {
   const int32_t *type_o;  // material type
   const double *inv_r_o;  // 1.0 / (double)radius, for the divisions of c/main.c:229 (div_f32_by)
   const uint8_t *group_real;   // n_pad/8 entries: real (non-pad) spheres per group
-  const uint32_t *round_real;  // n_pad/16 entries: real spheres in the round's two groups (byte 0, byte 1); dwords so
-                               // that the wave-uniform read is a scalar load
   uint32_t n, n_pad;
   float sigma0, sigma1;   // per-ray growth of the group boxes (rt_core.h, rt_cluster.h)
   uint32_t n_full;        // scan positions up to the last real sphere, rounded up to a round (16): what a
@@ -175,9 +173,6 @@ __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds
 
 // What a wave carries through one scan.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-// read-only for the whole launch and read at wave-uniform addresses: through the constant address space the
-// compiler turns such reads into scalar loads
-typedef const __attribute__((address_space(4))) uint32_t const_u32;
 
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
@@ -1312,7 +1307,6 @@ struct rt_ctx {
   DevBuf<float4> filter, boxes, sboxes, exact, geom_o, mat_o;
   DevBuf<int32_t> type_o;
   DevBuf<uint32_t> orig;
-  DevBuf<uint32_t> round_real;
   DevBuf<double> inv_r_o;
   DevBuf<uint8_t> group_real;
   uint32_t n = 0, n_pad = 0, n_full = 0;
@@ -1351,7 +1345,7 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->group_real.p, c->round_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
 }
 
 size_t scan_lds_bytes(uint32_t entries) {
@@ -1575,7 +1569,6 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->boxes.release();
   c->sboxes.release();
   c->orig.release();
-  c->round_real.release();
   c->inv_r_o.release();
   c->group_real.release();
   c->exact.release();
@@ -1646,7 +1639,6 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   std::vector<float4> filter(n_pad), exact(n_pad), boxes(3 * (n_pad / 16)), sboxes(3 * (n_pad / 64)), geom_o(n), mat_o(n);
   std::vector<int32_t> type_o(n);
   std::vector<double> inv_r_o(n);
-  std::vector<uint32_t> round_real(n_pad / 16);
   std::vector<FilterSphere> fs(n_pad);
   for (size_t i = 0; i < n; ++i) {
     const rt_sphere &s = spheres[i];
@@ -1676,7 +1668,6 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     boxes[3 * (g / 2)] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
     boxes[3 * (g / 2) + 1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
     boxes[3 * (g / 2) + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
-    round_real[g / 2] = (uint32_t)(L.real_in_group[g] | (L.real_in_group[g + 1] << 8));
   }
   for (uint32_t q = 0; q < n_pad / 64; ++q) {
     const GroupBox &b0 = L.supers[2 * q], &b1 = L.supers[2 * q + 1];
@@ -1687,7 +1678,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   int rc;
   if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(3 * (n_pad / 64))) || (rc = c->exact.reserve(n_pad)) ||
       (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
-      (rc = c->orig.reserve(n_pad)) || (rc = c->round_real.reserve(n_pad / 16)) || (rc = c->inv_r_o.reserve(n)) || (rc = c->group_real.reserve(n_pad / 8)))
+      (rc = c->orig.reserve(n_pad)) || (rc = c->inv_r_o.reserve(n)) || (rc = c->group_real.reserve(n_pad / 8)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
@@ -1700,7 +1691,6 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->inv_r_o.p, inv_r_o.data(), n * sizeof(double), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->group_real.p, L.real_in_group.data(), n_pad / 8, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->round_real.p, round_real.data(), (n_pad / 16) * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
   c->n_pad = n_pad;
   c->sigma0 = L.sigma0;
