@@ -134,9 +134,15 @@ __device__ __forceinline__ FilterRay dead_ray() {
 // wave: the list of (lane, group) pairs whose box test passed and await the
 // sphere filter, and the list of (lane, sphere) pairs that passed the filter
 // and await exact evaluation.
-constexpr uint32_t kWaveListCap = 768;              // (lane, sphere) entries per wave
-constexpr uint32_t kWaveListFlush = kWaveListCap - 64u * kChunk;   // a pass adds at most 64*kChunk: drain above this
-constexpr uint32_t kPairListCap = 512;              // (lane, group) entries per wave, 16 bits each
+// (lane, sphere) entries per wave.  The full scan adds up to 64 * kChunk per chunk and drains when fewer
+// are free; the culled scan looks at what a pass produced before appending it (filter_listed_pairs) and
+// gets by with a list that 32 lanes' worth of entries fit.
+constexpr uint32_t kWaveListCapFull = 768, kWaveListCapCull = 320;
+constexpr uint32_t wave_list_cap(bool cull) { return cull ? kWaveListCapCull : kWaveListCapFull; }
+constexpr uint32_t kWaveListFlushFull = kWaveListCapFull - 64u * kChunk;   // drain above this before a chunk
+static_assert(kWaveListCapFull >= 64u * kChunk && kWaveListCapCull >= 32u * kChunk, "list too short");
+constexpr uint32_t kPairListCap = 288;              // (lane, group) entries per wave, 16 bits each (with this the
+                                                    // workgroup's LDS is 31,936 bytes: five fit a CU's 160 KiB in 1280-byte units)
 constexpr uint32_t kPairListFlush = kPairListCap - 2u * 64u;       // a round adds at most two groups for 64 lanes
 
 struct ScanLds {
@@ -145,11 +151,12 @@ struct ScanLds {
   float4 *sboxes;                // 3 per pair of super-groups (64 spheres)
   float4 *rays;                  // 3 per lane: {A, a}, {B, -(B.B) of the filter}, {1/a as a double, A.B, naaa of the filter}
   unsigned long long *best;      // 1 per lane
-  uint32_t *wlist;               // kWaveListCap per wave: (owner lane << 16) | scan position
+  uint32_t *wlist;               // wave_list_cap() per wave: (owner lane << 16) | scan position
   uint16_t *plist;               // kPairListCap per wave: (group within the batch << 6) | owner lane
   uint8_t *real8;                // per group of the batch: its real (non-pad) spheres
 };
 
+template <bool kCull>
 __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entries) {
   ScanLds l;
   l.pairs = reinterpret_cast<float4 *>(smem);
@@ -158,7 +165,7 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
   l.rays = l.sboxes + 3u * (entries / 64u);
   l.best = reinterpret_cast<unsigned long long *>(l.rays + 3 * kBlockThreads);
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
-  l.plist = reinterpret_cast<uint16_t *>(l.wlist + (kBlockThreads / 64) * kWaveListCap);
+  l.plist = reinterpret_cast<uint16_t *>(l.wlist + (kBlockThreads / 64) * wave_list_cap(kCull));
   l.real8 = reinterpret_cast<uint8_t *>(l.plist + (kBlockThreads / 64) * kPairListCap);
   return l;
 }
@@ -359,6 +366,34 @@ __device__ __forceinline__ void box_pair(const BoxRayP &r, const float4 (&q)[3],
   }
 }
 
+// The same for two pairs (half a group): sixteen instructions, four chains.  The culled scan filters a
+// group in two halves to stay inside the register budget of five waves per SIMD.
+__device__ __forceinline__ void filter_two_pairs(const FilterRayP &f, const float4 (&q)[4], f32x2 &d0, f32x2 &d1) {
+  f32x2 t0, t1;
+  const f32x2 cx0 = {q[0].x, q[0].y}, cy0 = {q[0].z, q[0].w}, cz0 = {q[1].x, q[1].y}, kp0 = {q[1].z, q[1].w};
+  const f32x2 cx1 = {q[2].x, q[2].y}, cy1 = {q[2].z, q[2].w}, cz1 = {q[3].x, q[3].y}, kp1 = {q[3].z, q[3].w};
+  RT_ASM("v_pk_fma_f32 %0, %4, %11, %4 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+         "v_pk_fma_f32 %1, %4, %15, %4 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+         "v_pk_fma_f32 %2, %6, %11, %12 " RT_BCAST_LO_S0 "\n\t"
+         "v_pk_fma_f32 %3, %6, %15, %16 " RT_BCAST_LO_S0 "\n\t"
+         "v_pk_fma_f32 %0, %5, %10, %0 " RT_BCAST_HI_S0 "\n\t"
+         "v_pk_fma_f32 %1, %5, %14, %1 " RT_BCAST_HI_S0 "\n\t"
+         "v_pk_fma_f32 %2, %7, %10, %2 " RT_BCAST_HI_S0 "\n\t"
+         "v_pk_fma_f32 %3, %7, %14, %3 " RT_BCAST_HI_S0 "\n\t"
+         "v_pk_fma_f32 %0, %5, %9, %0 " RT_BCAST_LO_S0 "\n\t"
+         "v_pk_fma_f32 %1, %5, %13, %1 " RT_BCAST_LO_S0 "\n\t"
+         "v_pk_fma_f32 %2, %7, %9, %2 " RT_BCAST_LO_S0 "\n\t"
+         "v_pk_fma_f32 %3, %7, %13, %3 " RT_BCAST_LO_S0 "\n\t"
+         "v_pk_fma_f32 %0, %0, %0, %8 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+         "v_pk_fma_f32 %1, %1, %1, %8 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+         "v_pk_fma_f32 %0, %6, %2, %0 " RT_BCAST_HI_S0 "\n\t"
+         "v_pk_fma_f32 %1, %6, %3, %1 " RT_BCAST_HI_S0
+         : "=&v"(d0), "=&v"(d1), "=&v"(t0), "=&v"(t1)
+         : "v"(f.p1), "v"(f.p0), "v"(f.p3), "v"(f.p2), "v"(f.p4),             // %4 .. %8
+           "v"(cx0), "v"(cy0), "v"(cz0), "v"(kp0),                            // %9 .. %12
+           "v"(cx1), "v"(cy1), "v"(cz1), "v"(kp1));                           // %13 .. %16
+}
+
 // One group of kChunk spheres = kChunk float4 of the pair image (see scan_batch).
 struct ChunkRegs {
   float4 q[kChunk];
@@ -418,10 +453,10 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
 // to the (lane, sphere) list under the owner's name.
 __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const float4 *lds_pairs, const uint8_t *lds_real8,
                                                     uint32_t base, WaveScan &w, HitState &h) {
-  for (uint32_t e0 = 0; e0 < w.pcnt; e0 += 64u) {
-    if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);   // rare: the list usually lasts the whole scan
+  uint32_t width = 64u;   // pairs per pass
+  for (uint32_t e0 = 0; e0 < w.pcnt;) {
     const uint32_t e = e0 + w.lane;
-    const bool valid = e < w.pcnt;
+    const bool valid = w.lane < width && e < w.pcnt;
     const uint32_t entry = valid ? (uint32_t)*(lds_u16 *)(uintptr_t)(w.plist_off + (e << 1)) : 0u;
     const uint32_t owner = entry & 63u, grp = entry >> 6;
     const float4 ra = w.rays[3 * owner], rb = w.rays[3 * owner + 1], rc = w.rays[3 * owner + 2];
@@ -431,31 +466,43 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
     f.p2 = f32x2{-2.0f * ra.x, -2.0f * ra.y};
     f.p3 = f32x2{-2.0f * ra.z, rb.w};
     f.p4 = f32x2{rc.w, 0.0f};
-    ChunkRegs r;
-    load_chunk(r, lds_pairs, grp * kChunk);
     f32x2 d[kChunk / 2];
-    filter_four_pairs(f, r.q, d);
-#if RT_EXP == 12
-    {
-      f32x2 d2[kChunk / 2];
-      filter_four_pairs(f, r.q, d2);
-      asm volatile("" ::"v"(d2[0]), "v"(d2[1]), "v"(d2[2]), "v"(d2[3]));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float4 *src = lds_pairs + grp * kChunk + 4 * half;
+      const float4 q[4] = {src[0], src[1], src[2], src[3]};
+      filter_two_pairs(f, q, d[2 * half], d[2 * half + 1]);
     }
-#endif
-    if (valid) h.lane_tests += lds_real8[grp];
     // first word of this lane's entries: owner | scan position of the group's first sphere
     const uint32_t word0 = (owner << 16) | (base + grp * kChunk);
     const unsigned long long valid_mask = __ballot(valid);   // (a scalar AND per sphere instead of a vector select)
+    // Eight compares into eight scalar masks, OR-ed on the scalar unit, one branch
+    // for the whole pass: no branch waits on a vector compare of its own.
     unsigned long long m[kChunk];
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) m[u] = __ballot(d[u >> 1][u & 1] > 0.0f) & valid_mask;
     const unsigned long long any = ((m[0] | m[1]) | (m[2] | m[3])) | ((m[4] | m[5]) | (m[6] | m[7]));
     if (any != 0ull) {
       asm volatile("");  // (keeps the block a branch target; without it the nested ifs are merged)
+      // A bounce usually lists about 120 spheres in all.  Should this pass's not fit, the list is
+      // drained first; should they be more than the whole list, the pass is done again for 32 pairs,
+      // which cannot list more than 32 * kChunk.
+      uint32_t total = 0;
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) total += (uint32_t)__popcll(m[u]);
+      if (w.wcnt + total > kWaveListCapCull) {
+        if (total > kWaveListCapCull) {
+          width = 32u;
+          continue;
+        }
+        drain_wave(sc, w, h);
+      }
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) {
         if (m[u] != 0ull) {
           asm volatile("");
+          // address = scalar (list base + 4 * count so far) + 4 * (passing lanes below this one):
+          // four vector operations per listed sphere
           const uint32_t rank =
               __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
           uint32_t tail = w.wlist_off + (w.wcnt << 2);
@@ -466,6 +513,9 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
         }
       }
     }
+    if (valid) h.lane_tests += lds_real8[grp];
+    e0 += width;
+    width = 64u;
   }
   w.pcnt = 0;
 }
@@ -495,11 +545,11 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     load_chunk(ra, lds_pairs, 0);
     for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
       load_chunk(rb, lds_pairs, i0 + kChunk);
-      if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);   // rare: the list usually lasts the whole scan
+      if (w.wcnt > kWaveListFlushFull) drain_wave(sc, w, h);   // rare: the list usually lasts the whole scan
       filter_chunk(ra, base + i0, fr, w);
       // the read past the end of the last round stays inside the image and is never used
       load_chunk(ra, lds_pairs, i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u);
-      if (w.wcnt > kWaveListFlush) drain_wave(sc, w, h);
+      if (w.wcnt > kWaveListFlushFull) drain_wave(sc, w, h);
       filter_chunk(rb, base + i0 + kChunk, fr, w);
     }
     return;
@@ -600,7 +650,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   const uint32_t wave_first = tid & ~63u;
   WaveScan w;
   w.wlist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
-      (int)(uint32_t)(uintptr_t)(lds_u32 *)(lds.wlist + (tid >> 6) * kWaveListCap));
+      (int)(uint32_t)(uintptr_t)(lds_u32 *)(lds.wlist + (tid >> 6) * wave_list_cap(kCull)));
   w.plist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
       (int)(uint32_t)(uintptr_t)(lds_u16 *)(lds.plist + (tid >> 6) * kPairListCap));
   w.rays = lds.rays + 3 * wave_first;
@@ -715,13 +765,15 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 // kProfile: also accumulate, per wave, the shader cycles spent in the scan, the
 // drain and the shading, and the number of live lanes per bounce iteration
 // (counters 4..9); selected by RT_FLAG_PROFILE, for diagnosis only.
-// (second launch-bound argument: four waves per SIMD, i.e. at most 128 VGPRs)
+// (second launch-bound argument: waves per SIMD.  The culled scan of an LDS-resident scene fits 96 VGPRs
+// and, with its short lists, 32,000 bytes of LDS, so five workgroups share a CU; the other variants keep
+// four, i.e. at most 128 VGPRs.)
 template <bool kBatched, bool kCull, bool kProfile>
-__global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs args) {
+__global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void trace_kernel(const TraceArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DeviceScene &sc = args.sc;
   const rt_job &job = args.geo.job;
-  const ScanLds lds = carve_lds(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
+  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -931,8 +983,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void trace_kernel(const TraceArgs
     }
     // ---- next trip, or the end: nothing to trace and nothing left to hand out
     if (kBatched) {
-      work = __syncthreads_or(alive ? 1 : 0) != 0;
-      if (!work && __syncthreads_and(exhausted ? 1 : 0)) break;
+      // (the votes are the same in every lane; readfirstlane tells the compiler so)
+      work = __builtin_amdgcn_readfirstlane(__syncthreads_or(alive ? 1 : 0)) != 0;
+      if (!work && __builtin_amdgcn_readfirstlane(__syncthreads_and(exhausted ? 1 : 0))) break;
     } else {
       work = wave_any(alive);
       if (!work && exhausted) break;
@@ -1100,7 +1153,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t qcnt[4], qbase[4];
   const DeviceScene &sc = args.sc;
-  const ScanLds lds = carve_lds(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
+  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid < 4) qcnt[tid] = 0;
   if (!kBatched) stage_batch(sc, lds, 0u, sc.n_pad, tid);
@@ -1116,7 +1169,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
     q[sub] = -1;
     pos[sub] = 0;
     if (kBatched) {
-      if (!__syncthreads_or(alive ? 1 : 0)) continue;
+      if (!__builtin_amdgcn_readfirstlane(__syncthreads_or(alive ? 1 : 0))) continue;   // (same vote in every lane)
     } else {
       if (!wave_any(alive)) continue;
     }
@@ -1230,7 +1283,7 @@ template <bool kCull>
 __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene sc, const float *rays, uint32_t n_rays,
                                                                      float tmin, float tmax, int32_t *index, float *t) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const ScanLds lds = carve_lds(smem, kMaxLdsSpheres);
+  const ScanLds lds = carve_lds<kCull>(smem, kMaxLdsSpheres);
   const uint32_t tid = threadIdx.x;
   const uint32_t r = blockIdx.x * kBlockThreads + tid;
   const bool alive = r < n_rays;
@@ -1348,13 +1401,13 @@ DeviceScene scene_view(const rt_ctx *c) {
   return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
 }
 
-size_t scan_lds_bytes(uint32_t entries) {
+size_t scan_lds_bytes(uint32_t entries, bool cull) {
   return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u) * sizeof(float4) +  // pair image, boxes
          (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
-         (size_t)(kBlockThreads / 64) * (kWaveListCap * sizeof(uint32_t) + kPairListCap * sizeof(uint16_t)) +  // wave lists
+         (size_t)(kBlockThreads / 64) * (wave_list_cap(cull) * sizeof(uint32_t) + kPairListCap * sizeof(uint16_t)) +  // wave lists
          (size_t)((entries / 8u + 15u) & ~15u);                                              // real spheres per group
 }
-size_t trace_lds_bytes(uint32_t n_pad) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres); }
+size_t trace_lds_bytes(uint32_t n_pad, bool cull) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres, cull); }
 
 // samples per launch: the radiance buffer holds batch * pixels float4 and is
 // kept under kRadBudgetBytes
@@ -1430,11 +1483,14 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
   t.rad = c->rad.p;
   t.queue = c->queue.p;
   t.counters = c->counters.p;
-  const size_t lds = trace_lds_bytes(c->n_pad);
+  size_t lds = trace_lds_bytes(c->n_pad, (job->flags & RT_FLAG_FULL_SCAN) == 0);
+#if RT_EXP == 41   // occupancy experiment: pad the LDS request so that only three workgroups fit a CU
+  lds += 10240;
+#endif
   const bool batched = c->n_pad > kMaxLdsSpheres, profile = (job->flags & RT_FLAG_PROFILE) != 0;
   // persistent workgroups: enough to fill every CU at the kernel's occupancy;
   // surplus ones find the queue empty and leave
-  const dim3 grid((unsigned)(c->num_cus * 4)), block(kBlockThreads);
+  const dim3 grid((unsigned)(c->num_cus * 5)), block(kBlockThreads);
 
   const int slot = (int)(c->renders % rt_ctx::kHistory);
   auto &pairs = c->trace_events[slot];
@@ -1807,7 +1863,7 @@ int rt_debug_closest_hit(rt_ctx *c, const float *rays, size_t n_rays, float tmin
   }
   hipError_t e = hipMemcpy(d_rays.p, rays, 6 * n_rays * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    size_t lds = scan_lds_bytes(kMaxLdsSpheres);
+    size_t lds = scan_lds_bytes(kMaxLdsSpheres, true);
     uint32_t blocks = (uint32_t)((n_rays + kBlockThreads - 1) / kBlockThreads);
     hipLaunchKernelGGL(closest_hit_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds, c->stream, scene_view(c), d_rays.p,
                        (uint32_t)n_rays, tmin, tmax, d_idx.p, d_t.p);

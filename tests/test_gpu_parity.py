@@ -157,6 +157,40 @@ def test_degenerate_spheres_and_rays_do_not_break_the_scan(renderer, rt, oracle)
     assert_parity(got, want)
 
 
+@pytest.mark.parametrize("flags", [0, 2])
+def test_nested_shells_overflow_the_candidate_lists(renderer, rt, oracle, flags):
+    """48 concentric spheres of nearly the same radius: every ray aimed at the centre passes the filter for
+    every sphere, so a wave produces 64 x 8 candidates per filter pass -- more than its candidate list holds
+    in the culled scan -- and the lists must be drained and passes split without losing or doubling an entry."""
+    sc = rt.random_scene()[:48].copy()
+    sc["center"][:] = (0.0, 1.0, 0.0)
+    sc["radius"][:] = 1.0 + 1e-3 * np.arange(48, dtype=np.float32)[::-1]   # (the innermost has the highest index)
+    renderer.upload(sc)
+    rng = np.random.default_rng(31)
+    out = rng.normal(size=(2048, 3))
+    out /= np.linalg.norm(out, axis=1, keepdims=True)
+    origin = np.array([0.0, 1.0, 0.0]) + out * rng.uniform(2.0, 6.0, size=(2048, 1))
+    direction = -out * rng.uniform(0.5, 2.0, size=(2048, 1)) + rng.normal(scale=0.02, size=(2048, 3))
+    inside = np.concatenate([np.tile([0.0, 1.0, 0.0], (512, 1)) + rng.normal(scale=0.1, size=(512, 3)),
+                             rng.normal(size=(512, 3))], axis=1)
+    rays = np.concatenate([np.concatenate([origin, direction], axis=1), inside]).astype(np.float32)
+    idx, t = renderer.closest_hit(rays)
+    osc = as_oracle_scene(sc)
+    hits = 0
+    for i, r in enumerate(rays):
+        oi, ot, _, _ = oracle.hit_scene(osc, r[:3], r[3:])
+        assert oi == idx[i], (i, oi, idx[i])
+        if oi >= 0:
+            hits += 1
+            assert ot.tobytes() == t[i].tobytes()
+    assert hits > 2000
+    nx, ny, spp = 96, 54, 4
+    cam = rt.camera_default(nx, ny)
+    got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=6, flags=flags))
+    want = oracle.render_det(cam.as_array(), osc, nx, ny, spp, seed=6, host_threads=16)
+    assert_parity(got, want)
+
+
 def test_ragged_sizes_depth_and_single_sample(renderer, rt, oracle):
     sc = rt.random_scene()
     renderer.upload(sc)
