@@ -81,24 +81,35 @@ RT_HD uint32_t path_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
 // r/(2^31-1) = r*2^-31 * (1 + 2^-31 + 2^-62 + ...).  x = r*2^-31 is exact; one
 // fused multiply-add x*(2^-31 + 2^-62) + x rounds a value that differs from
 // the quotient by less than x*2^-92, far inside the gap a 31-bit r leaves
-// around any rounding boundary.  tests/test_rng_exhaustive checks all 2^31
-// values against the division.
+// around any rounding boundary.  The host tests check all 2^31 values against
+// the division.
 RT_HD double unit_from_bits(uint32_t r31) {
   double x = (double)r31 * 4.656612873077392578125e-10;  // 2^-31
   const double tail = 4.656612873077392578125e-10 + 2.1684043449710088680149056017398834228515625e-19;
   return __builtin_fma(x, tail, x);
 }
 
+// (float)(r / (2^31 - 1)) where the draw is narrowed at once (c/vec.c:67-68):
+// one product by 2^-31 (1 + 2^-31), the double nearest 1/(2^31 - 1).  The
+// product is not always the correctly rounded double quotient, but it lies on
+// the same side of every float rounding boundary; the host tests check all
+// 2^31 values.
+RT_HD float unit_float_from_bits(uint32_t r31) { return (float)((double)r31 * 0x1.00000002p-31); }
+
 struct Rng {
   uint32_t key;
   uint32_t k;
 };
 
-RT_HD double next_uniform(Rng &g) {
+RT_HD uint32_t next_bits(Rng &g) {
   uint32_t r = mix32(g.key + g.k * 0x9e3779b9u) >> 1;
   g.k++;
-  return unit_from_bits(r);
+  return r;
 }
+
+RT_HD double next_uniform(Rng &g) { return unit_from_bits(next_bits(g)); }
+
+RT_HD float next_uniform_float(Rng &g) { return unit_float_from_bits(next_bits(g)); }
 
 // c/vec.c:64-72.  The reference tests norm = sqrtf(s) against 1 and
 // FLT_EPSILON; for a correctly rounded square root sqrtf(s) < 1 exactly when
@@ -106,9 +117,9 @@ RT_HD double next_uniform(Rng &g) {
 // 2^-23 exactly when s < 2^-46, so the loop tests s itself.
 // one attempt: three draws, the candidate, and whether the loop would keep it
 RT_HD bool unit_ball_try(Rng &g, V3 &u) {
-  float ux = (float)next_uniform(g);
-  float uy = (float)next_uniform(g);
-  float uz = (float)next_uniform(g);
+  float ux = next_uniform_float(g);
+  float uy = next_uniform_float(g);
+  float uz = next_uniform_float(g);
   // 2*x - 1 (c/vec.c:67-68): the product is exact, so one fused operation rounds like the two
   u = v3(rt_fma(2.0f, ux, -1.0f), rt_fma(2.0f, uy, -1.0f), rt_fma(2.0f, uz, -1.0f));
   float s = u.x * u.x + u.y * u.y + u.z * u.z;

@@ -277,6 +277,18 @@ uint64_t core_reciprocal_mismatches(uint32_t first, uint32_t last) {
   return bad;
 }
 
+// draws first..last: the double and the float form of r / (2^31 - 1) against the division (c/rand.c:15)
+uint64_t core_unit_mismatches(uint32_t first, uint32_t last) {
+  uint64_t bad = 0;
+  for (uint64_t b = first; b <= last; b++) {
+    const uint32_t r = (uint32_t)b;
+    const double want = (double)r / 2147483647.0, got = unit_from_bits(r);
+    const float wantf = (float)want, gotf = unit_float_from_bits(r);
+    if (memcmp(&want, &got, 8) != 0 || memcmp(&wantf, &gotf, 4) != 0) bad++;
+  }
+  return bad;
+}
+
 uint64_t core_float_division_mismatches(uint64_t n, uint64_t seed) {
   uint64_t s = seed * 0x9e3779b97f4a7c15ull + 88172645463325252ull, bad = 0;
   auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };

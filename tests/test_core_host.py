@@ -110,6 +110,13 @@ def test_float_reciprocal_equals_the_narrowed_double_reciprocal(core):
     assert core.core_reciprocal_mismatches(C.c_uint32(0), C.c_uint32(0x7F800000)) == 0
 
 
+def test_draw_conversion_is_the_division_for_every_draw(core):
+    """r / (2^31 - 1) as the kernels compute it (one fused multiply-add for the double, one product for the
+    narrowed float) against the division of c/rand.c:15, for all 2^31 values of r."""
+    core.core_unit_mismatches.restype = C.c_uint64
+    assert core.core_unit_mismatches(C.c_uint32(0), C.c_uint32(0x7FFFFFFF)) == 0
+
+
 def test_division_by_a_reused_float_divisor(core):
     core.core_float_division_mismatches.restype = C.c_uint64
     assert core.core_float_division_mismatches(C.c_uint64(20_000_000), C.c_uint64(3)) == 0
