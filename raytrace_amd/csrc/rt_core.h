@@ -101,35 +101,63 @@ struct Rng {
   uint32_t k;
 };
 
+// the 31 bits of the draw whose hash input is x = key + k * 0x9e3779b9
+RT_HD uint32_t bits_at(uint32_t x) {
+  x = mix32(x);
+#ifdef __HIP_DEVICE_COMPILE__
+  // keep mix32's last step (one instruction with a 16-bit operand select) apart from the shift below;
+  // merged, the two become (x >> 17) ^ (x >> 1), three instructions
+  asm("" : "+v"(x));
+#endif
+  return x >> 1;
+}
+
 RT_HD uint32_t next_bits(Rng &g) {
-  uint32_t r = mix32(g.key + g.k * 0x9e3779b9u) >> 1;
+  const uint32_t r = bits_at(g.key + g.k * 0x9e3779b9u);
   g.k++;
   return r;
 }
 
 RT_HD double next_uniform(Rng &g) { return unit_from_bits(next_bits(g)); }
 
-RT_HD float next_uniform_float(Rng &g) { return unit_float_from_bits(next_bits(g)); }
 
 // c/vec.c:64-72.  The reference tests norm = sqrtf(s) against 1 and
 // FLT_EPSILON; for a correctly rounded square root sqrtf(s) < 1 exactly when
 // s < 1 (the float below 1 has a root that rounds below 1) and sqrtf(s) <
 // 2^-23 exactly when s < 2^-46, so the loop tests s itself.
-// one attempt: three draws, the candidate, and whether the loop would keep it
-RT_HD bool unit_ball_try(Rng &g, V3 &u) {
-  float ux = next_uniform_float(g);
-  float uy = next_uniform_float(g);
-  float uz = next_uniform_float(g);
+// one attempt from the three draws whose hash inputs are x, x + w, x + 2w (w = 0x9e3779b9): the
+// candidate, and whether the loop would keep it
+RT_HD bool unit_ball_try_at(uint32_t x, V3 &u) {
+  float ux = unit_float_from_bits(bits_at(x));
+  float uy = unit_float_from_bits(bits_at(x + 0x9e3779b9u));
+  float uz = unit_float_from_bits(bits_at(x + 2u * 0x9e3779b9u));
   // 2*x - 1 (c/vec.c:67-68): the product is exact, so one fused operation rounds like the two
   u = v3(rt_fma(2.0f, ux, -1.0f), rt_fma(2.0f, uy, -1.0f), rt_fma(2.0f, uz, -1.0f));
   float s = u.x * u.x + u.y * u.y + u.z * u.z;
   return s < 1.0f && !(s < 1.4210854715202004e-14f);   // 2^-46
 }
 
+RT_HD bool unit_ball_try(Rng &g, V3 &u) {
+  const bool keep = unit_ball_try_at(g.key + g.k * 0x9e3779b9u, u);
+  g.k += 3;
+  return keep;
+}
+
+// The loop steps the hash input itself; the draw count follows from it at the end (the step is odd,
+// hence invertible modulo 2^32), which leaves the loop one running value instead of two.
 RT_HD V3 unit_ball(Rng &g) {
   V3 u;
-  while (!unit_ball_try(g, u)) {
-  }
+  uint32_t x = g.key + (g.k - 3u) * 0x9e3779b9u;
+  do {
+#ifdef __HIP_DEVICE_COMPILE__
+    // (in place, at the top of the trip: moved to the bottom by the compiler, the sum needs a register
+    // copy per trip to keep the value the lanes that leave the loop hold)
+    asm("v_add_u32 %0, %1, %0" : "+v"(x) : "s"(3u * 0x9e3779b9u));
+#else
+    x += 3u * 0x9e3779b9u;
+#endif
+  } while (!unit_ball_try_at(x, u));
+  g.k = (x - g.key) * 0x144cbc89u + 3u;   // 0x9e3779b9 * 0x144cbc89 = 1 (mod 2^32)
   return u;
 }
 

@@ -944,6 +944,13 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
     V3 ball = v3(0, 0, 0);
     RT_STAGE_BEGIN(31);
     if (pending != kNone) ball = unit_ball(g);
+#if RT_EXP == 14   // the rejection loop a second time, from a generator state that gives other trip counts
+    if (pending != kNone) {
+      Rng g2{g.key ^ 0x5bd1e995u, g.k};
+      const V3 b2 = unit_ball(g2);
+      asm volatile("" ::"v"(b2.x), "v"(b2.y), "v"(b2.z));
+    }
+#endif
     RT_STAGE_END(31);
     // ---- (5): shade, second part / camera ray
     RT_STAGE_BEGIN(34);
