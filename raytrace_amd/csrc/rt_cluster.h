@@ -21,7 +21,11 @@
 // |A|^2 on the half extents; this file computes sigma0 and sigma1.  Four
 // consecutive groups form a super-group whose box (the box around the four,
 // widened once more for its own slab arithmetic) is tested first; a wave skips
-// the four box tests of a super-group no lane's ray can touch.
+// the four box tests of a super-group no lane's ray can touch.  Scenes too
+// large to stay in LDS are scanned in batches of `batch_spheres` consecutive
+// scan positions; each batch has a box of its own (around its super-group
+// boxes, widened the same way), and a workgroup skips the batches none of its
+// rays can touch.
 //
 // Scenes like the reference's are flat fields of small spheres on one huge
 // one; boxes around neighbours are flat too, so most rays that fly over a
@@ -49,6 +53,7 @@ struct Layout {
   std::vector<uint32_t> order;        // scan position -> original index, 0xffffffff for a pad
   std::vector<rtcore::GroupBox> boxes;  // one per group; h = +1e30 means "always scan", -1e30 "never"
   std::vector<rtcore::GroupBox> supers; // one per kSuper consecutive groups: the box around their boxes
+  std::vector<rtcore::GroupBox> batches; // one per batch_spheres scan positions (an even number of them): the box around its super-groups
   std::vector<uint8_t> real_in_group; // real (non-pad) spheres per group
   uint32_t n_scan = 0;                // = order.size(), a multiple of 2*kSuper*kGroup (a pair of super-groups)
   float sigma0 = 0.0f, sigma1 = 0.0f; // per-ray growth of the half extents: 1 + sigma0 + sigma1 |A|^2 (rt_core.h)
@@ -60,7 +65,8 @@ inline float round_up_to_float(double v) {
   return f;
 }
 
-inline Layout build_layout(const rt_sphere *s, size_t n) {
+// batch_spheres: a multiple of 2 * kSuper * kGroup
+inline Layout build_layout(const rt_sphere *s, size_t n, size_t batch_spheres) {
   Layout L;
   std::vector<float> radii(n);
   for (size_t i = 0; i < n; ++i) radii[i] = s[i].radius;
@@ -151,11 +157,12 @@ inline Layout build_layout(const rt_sphere *s, size_t n) {
   for (size_t k = 0; k < regular.size(); k += kGroup)
     emit_group(&regular[k], std::min<size_t>(kGroup, regular.size() - k), false);
   while (L.boxes.size() % (2 * kSuper)) emit_group(nullptr, 0, false);   // whole pairs of super-groups
-  for (size_t g0 = 0; g0 < L.boxes.size(); g0 += kSuper) {
+  // the box around boxes [first, last) of `from` ("always" if one of them is, "never" if all are)
+  auto box_around = [&](const std::vector<rtcore::GroupBox> &from, size_t first, size_t last) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     bool always = false, any = false;
-    for (size_t g = g0; g < g0 + kSuper; ++g) {
-      const rtcore::GroupBox &b = L.boxes[g];
+    for (size_t g = first; g < last && g < from.size(); ++g) {
+      const rtcore::GroupBox &b = from[g];
       if (b.hx > 1.0e29f) always = true;
       if (b.hx > 1.0e29f || b.hx < 0.0f) continue;
       any = true;
@@ -167,11 +174,14 @@ inline Layout build_layout(const rt_sphere *s, size_t n) {
     }
     if (always || !any) {
       const float h = always ? 1.0e30f : -1.0e30f;
-      L.supers.push_back(rtcore::GroupBox{0.0f, 0.0f, 0.0f, h, h, h});
-    } else {
-      L.supers.push_back(widened_box(lo, hi));
+      return rtcore::GroupBox{0.0f, 0.0f, 0.0f, h, h, h};
     }
-  }
+    return widened_box(lo, hi);
+  };
+  for (size_t g0 = 0; g0 < L.boxes.size(); g0 += kSuper) L.supers.push_back(box_around(L.boxes, g0, g0 + kSuper));
+  const size_t supers_per_batch = batch_spheres / (kSuper * kGroup);
+  for (size_t q0 = 0; q0 < L.supers.size(); q0 += supers_per_batch) L.batches.push_back(box_around(L.supers, q0, q0 + supers_per_batch));
+  if (L.batches.size() % 2) L.batches.push_back(rtcore::GroupBox{0.0f, 0.0f, 0.0f, -1.0e30f, -1.0e30f, -1.0e30f});
   L.n_scan = (uint32_t)L.order.size();
   if (h_min < 1e299) {   // (else there is nothing to cull)
     L.sigma0 = round_up_to_float(std::ldexp(1.0, -19) / h_min);

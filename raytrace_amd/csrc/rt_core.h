@@ -143,21 +143,10 @@ RT_HD bool unit_ball_try(Rng &g, V3 &u) {
   return keep;
 }
 
-// The loop steps the hash input itself; the draw count follows from it at the end (the step is odd,
-// hence invertible modulo 2^32), which leaves the loop one running value instead of two.
 RT_HD V3 unit_ball(Rng &g) {
   V3 u;
-  uint32_t x = g.key + (g.k - 3u) * 0x9e3779b9u;
-  do {
-#ifdef __HIP_DEVICE_COMPILE__
-    // (in place, at the top of the trip: moved to the bottom by the compiler, the sum needs a register
-    // copy per trip to keep the value the lanes that leave the loop hold)
-    asm("v_add_u32 %0, %1, %0" : "+v"(x) : "s"(3u * 0x9e3779b9u));
-#else
-    x += 3u * 0x9e3779b9u;
-#endif
-  } while (!unit_ball_try_at(x, u));
-  g.k = (x - g.key) * 0x144cbc89u + 3u;   // 0x9e3779b9 * 0x144cbc89 = 1 (mod 2^32)
+  while (!unit_ball_try(g, u)) {
+  }
   return u;
 }
 

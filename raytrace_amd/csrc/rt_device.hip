@@ -66,7 +66,9 @@ namespace {
 constexpr int kBlockThreads = 256;
 constexpr int kChunk = 8;             // spheres per unrolled filter group
 constexpr int kDrainEvery = 16;       // spheres per round of the scan (two groups)
-constexpr uint32_t kMaxLdsSpheres = 2048;  // 32 KiB of filter entries per staged batch
+constexpr uint32_t kMaxLdsSpheres = 2048;  // scan positions of a scene that stays in LDS for the whole kernel
+constexpr uint32_t kBatchSpheres = 512;    // larger scenes: scan positions per staged batch (the LDS footprint of
+                                           // a batch is that of the reference's final scene)
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
 constexpr int kNumCounters = 13;
 
@@ -74,7 +76,7 @@ constexpr int kNumCounters = 13;
 struct DeviceScene {
   const float4 *filter;   // n_pad entries, sphere pairs {cx0,cx1,cy0,cy1},{cz0,cz1,K'0,K'1}; pads never pass
   const float4 *boxes;    // 3 entries per round of two groups: {cx0,cx1,cy0,cy1},{cz0,cz1,hx0,hx1},{hy0,hy1,hz0,hz1}
-  const float4 *sboxes;   // 3 entries per pair of super-groups (64 spheres), same layout as boxes
+  const float4 *sboxes;   // 3 entries per pair of super-groups (64 spheres), same layout as boxes; then the batch boxes
   const float4 *exact;    // n_pad entries {cx, cy, cz, r*r}
   const uint32_t *orig;   // n_pad entries: index in the caller's list (ties go to the lowest), ~0 for pads
   // for shading, in the CALLER's order (n entries):
@@ -88,6 +90,10 @@ struct DeviceScene {
   uint32_t n_full;        // scan positions up to the last real sphere, rounded up to a round (16): what a
                           // scan without culling has to visit (the rest is padding)
 };
+
+// The boxes of the batches of a streamed scene follow the super-group boxes in the same array: 3 entries
+// per pair of batches (kBatchSpheres scan positions each), same layout.
+__device__ __host__ inline uint32_t batch_pairs(uint32_t n_pad) { return ((n_pad + kBatchSpheres - 1u) / kBatchSpheres + 1u) / 2u; }
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
@@ -154,6 +160,7 @@ struct ScanLds {
   uint32_t *wlist;               // wave_list_cap() per wave: (owner lane << 16) | scan position
   uint16_t *plist;               // kPairListCap per wave: (group within the batch << 6) | owner lane
   uint8_t *real8;                // per group of the batch: its real (non-pad) spheres
+  unsigned long long *bmask;     // 2 per wave: the batches the wave's rays can touch (streamed scenes)
 };
 
 template <bool kCull>
@@ -167,6 +174,7 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
   l.plist = reinterpret_cast<uint16_t *>(l.wlist + (kBlockThreads / 64) * wave_list_cap(kCull));
   l.real8 = reinterpret_cast<uint8_t *>(l.plist + (kBlockThreads / 64) * kPairListCap);
+  l.bmask = reinterpret_cast<unsigned long long *>(l.real8 + ((entries / 8u + 15u) & ~15u));
   return l;
 }
 
@@ -356,6 +364,36 @@ __device__ __forceinline__ void box_pair(const BoxRayP &r, const float4 (&q)[3],
          : "=&v"(nx), "=&v"(ny), "=&v"(nz), "=&v"(fx), "=&v"(fy), "=&v"(fz), "=&v"(mx), "=&v"(my), "=&v"(mz)
          : "v"(r.p0), "v"(r.p1), "v"(r.p2), "v"(r.p3), "v"(r.p4),          // %9 .. %13
            "v"(cx), "v"(cy), "v"(cz), "v"(hx), "v"(hy), "v"(hz));          // %14 .. %19
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float tn, tf, lim;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx[i]), "v"(ny[i]), "v"(nz[i]));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx[i]), "v"(fy[i]), "v"(fz[i]));
+    asm("v_max_f32 %0, 0, %1" : "=v"(lim) : "v"(tn));
+    pass[i] = tf >= lim;
+  }
+}
+
+// box_pair for two boxes held in scalar registers (the batch boxes of a streamed scene, read with scalar
+// loads): every instruction has one scalar operand, which is what the encoding allows.
+struct BoxPairS {
+  f32x2 cx, cy, cz, hx, hy, hz;
+};
+
+__device__ __forceinline__ void box_pair_scalar(const BoxRayP &r, const BoxPairS &b, bool (&pass)[2]) {
+  f32x2 nx, ny, nz, fx, fy, fz, mx, my, mz;
+  RT_ASM("v_pk_fma_f32 %6, %9, %14, %10 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+         "v_pk_fma_f32 %7, %9, %15, %11 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+         "v_pk_fma_f32 %8, %10, %16, %11 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
+         "v_pk_fma_f32 %0, %12, %17, %6 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+         "v_pk_fma_f32 %3, %12, %17, %6 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+         "v_pk_fma_f32 %1, %12, %18, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+         "v_pk_fma_f32 %4, %12, %18, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+         "v_pk_fma_f32 %2, %13, %19, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+         "v_pk_fma_f32 %5, %13, %19, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+         : "=&v"(nx), "=&v"(ny), "=&v"(nz), "=&v"(fx), "=&v"(fy), "=&v"(fz), "=&v"(mx), "=&v"(my), "=&v"(mz)
+         : "v"(r.p0), "v"(r.p1), "v"(r.p2), "v"(r.p3), "v"(r.p4),          // %9 .. %13
+           "s"(b.cx), "s"(b.cy), "s"(b.cz), "s"(b.hx), "s"(b.hy), "s"(b.hz));   // %14 .. %19
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float tn, tf, lim;
@@ -635,7 +673,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
 
 // Closest hit of the ray (A, B) of every lane of the workgroup against the
 // whole scene, within (tmin, tmax).  Unbatched: the scene is already resident
-// in LDS.  Batched: it is streamed through LDS in kMaxLdsSpheres pieces, which
+// in LDS.  Batched: it is streamed through LDS in kBatchSpheres pieces, which
 // needs every wave of the workgroup here together.  Lanes without a ray pass
 // dead_ray().
 template <bool kBatched, bool kCull, bool kProfile = false>
@@ -668,14 +706,63 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   lds.rays[3 * tid + 2] = make_float4(__int_as_float(__double2loint(inv_a)), __int_as_float(__double2hiint(inv_a)), f.ab, f.naaa);
   lds.best[tid] = (unsigned long long)__float_as_uint(tmax) << 32;
   if (kBatched) {
-    for (uint32_t base = 0; base < sc.n_pad; base += kMaxLdsSpheres) {
-      uint32_t count = min(kMaxLdsSpheres, sc.n_pad - base);
+    // Which batches to stage: those whose box some ray of the workgroup can touch.  Every lane tests
+    // its ray against every batch box (two per packed evaluation, the boxes read through the scalar
+    // cache one pair ahead); a wave's union goes to LDS, and after a barrier every wave holds the
+    // workgroup's union -- the same in all of them, as the barriers around the staging need.
+    unsigned long long want_lo = ~0ull, want_hi = ~0ull;   // (without culling: every batch)
+    if (kCull) {
+      typedef __attribute__((address_space(4))) const float *ScalarFloats;
+      const ScalarFloats bb = (ScalarFloats)(uintptr_t)(sc.sboxes + 3u * (sc.n_pad / 64u));
+      const uint32_t n_batch_pairs = batch_pairs(sc.n_pad);
+      const unsigned long long all_mask = __ballot(uncullable), live_mask = __ballot(alive);
+      unsigned long long mine_lo = 0ull, mine_hi = 0ull;
+      auto load_pair = [&](uint32_t q) {
+        const ScalarFloats e = bb + 12u * q;
+        return BoxPairS{f32x2{e[0], e[1]}, f32x2{e[2], e[3]}, f32x2{e[4], e[5]}, f32x2{e[6], e[7]}, f32x2{e[8], e[9]}, f32x2{e[10], e[11]}};
+      };
+      BoxPairS cur = load_pair(0u);
+      for (uint32_t q = 0; q < n_batch_pairs; ++q) {
+        const BoxPairS nxt = load_pair(q + 1u < n_batch_pairs ? q + 1u : 0u);
+        bool pass[2];
+        box_pair_scalar(br, cur, pass);
+        const unsigned long long m0 = __ballot(pass[0]) & live_mask, m1 = __ballot(pass[1]) & live_mask;
+        const unsigned long long bits = (unsigned long long)((m0 != 0ull ? 1u : 0u) | (m1 != 0ull ? 2u : 0u));
+        if (q < 32u) mine_lo |= bits << (2u * q);
+        else mine_hi |= bits << (2u * q - 64u);
+        cur = nxt;
+      }
+      if (all_mask != 0ull) mine_lo = mine_hi = ~0ull;
+      h.tests += 2u * n_batch_pairs;
+      if (w.lane == 0u) {
+        lds.bmask[2u * (tid >> 6)] = mine_lo;
+        lds.bmask[2u * (tid >> 6) + 1u] = mine_hi;
+      }
       __syncthreads();
-      stage_batch(sc, lds, base, count, tid);
-      __syncthreads();
-      // (without culling the trailing padding is not visited)
-      const uint32_t span = kCull ? count : (sc.n_full > base ? min(count, sc.n_full - base) : 0u);
-      scan_batch<kCull>(sc, lds, base, span, fr, br, alive, uncullable, w, h);
+      want_lo = (lds.bmask[0] | lds.bmask[2]) | (lds.bmask[4] | lds.bmask[6]);
+      want_hi = (lds.bmask[1] | lds.bmask[3]) | (lds.bmask[5] | lds.bmask[7]);
+      want_lo = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(want_lo >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)want_lo);
+      want_hi = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(want_hi >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)want_hi);
+    }
+    static_assert(kBlockThreads / 64 == 4, "four waves' masks are combined");
+    static_assert((kMaxSpheres + kBatchSpheres) / kBatchSpheres <= 128u, "two 64-bit masks");
+#pragma unroll 1
+    for (uint32_t half = 0; half < 2u; ++half) {
+      unsigned long long want = half ? want_hi : want_lo;
+      while (want != 0ull) {
+        const uint32_t base = (half * 64u + (uint32_t)__builtin_ctzll(want)) * kBatchSpheres;
+        want &= want - 1ull;
+        if (base >= sc.n_pad) break;   // (a mask with every bit set names batches that do not exist)
+        const uint32_t count = min(kBatchSpheres, sc.n_pad - base);
+        __syncthreads();
+        stage_batch(sc, lds, base, count, tid);
+        __syncthreads();
+        // (without culling the trailing padding is not visited)
+        const uint32_t span = kCull ? count : (sc.n_full > base ? min(count, sc.n_full - base) : 0u);
+        scan_batch<kCull>(sc, lds, base, span, fr, br, alive, uncullable, w, h);
+      }
     }
   } else {
     scan_batch<kCull>(sc, lds, 0u, kCull ? sc.n_pad : sc.n_full, fr, br, alive, uncullable, w, h);
@@ -773,7 +860,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   extern __shared__ __align__(16) unsigned char smem[];
   const DeviceScene &sc = args.sc;
   const rt_job &job = args.geo.job;
-  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
+  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? kBatchSpheres : sc.n_pad);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -1160,7 +1247,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t qcnt[4], qbase[4];
   const DeviceScene &sc = args.sc;
-  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? kMaxLdsSpheres : sc.n_pad);
+  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? kBatchSpheres : sc.n_pad);
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid < 4) qcnt[tid] = 0;
   if (!kBatched) stage_batch(sc, lds, 0u, sc.n_pad, tid);
@@ -1290,7 +1377,7 @@ template <bool kCull>
 __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene sc, const float *rays, uint32_t n_rays,
                                                                      float tmin, float tmax, int32_t *index, float *t) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const ScanLds lds = carve_lds<kCull>(smem, kMaxLdsSpheres);
+  const ScanLds lds = carve_lds<kCull>(smem, kBatchSpheres);
   const uint32_t tid = threadIdx.x;
   const uint32_t r = blockIdx.x * kBlockThreads + tid;
   const bool alive = r < n_rays;
@@ -1412,9 +1499,10 @@ size_t scan_lds_bytes(uint32_t entries, bool cull) {
   return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u) * sizeof(float4) +  // pair image, boxes
          (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
          (size_t)(kBlockThreads / 64) * (wave_list_cap(cull) * sizeof(uint32_t) + kPairListCap * sizeof(uint16_t)) +  // wave lists
-         (size_t)((entries / 8u + 15u) & ~15u);                                              // real spheres per group
+         (size_t)((entries / 8u + 15u) & ~15u) +                                            // real spheres per group
+         (size_t)(kBlockThreads / 64) * 2 * sizeof(unsigned long long);                      // batch masks
 }
-size_t trace_lds_bytes(uint32_t n_pad, bool cull) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kMaxLdsSpheres, cull); }
+size_t trace_lds_bytes(uint32_t n_pad, bool cull) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kBatchSpheres, cull); }
 
 // samples per launch: the radiance buffer holds batch * pixels float4 and is
 // kept under kRadBudgetBytes
@@ -1695,7 +1783,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   }
   RT_HIP(hipSetDevice(c->device));
   // scan order and group bounds (rt_cluster.h); everything below is in scan order
-  const rtcluster::Layout L = rtcluster::build_layout(spheres, n);
+  const rtcluster::Layout L = rtcluster::build_layout(spheres, n, kBatchSpheres);
   const uint32_t n_pad = L.n_scan;
   static_assert(rtcluster::kGroup == kChunk, "one group per chunk");
   if (n_pad > kMaxSpheres) return fail(RT_ERR_LIMIT, "too many spheres after padding");
@@ -1738,15 +1826,25 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     sboxes[3 * q + 1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
     sboxes[3 * q + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
   }
+  const uint32_t n_batch_pairs = (uint32_t)(L.batches.size() / 2);
+  if (n_batch_pairs != batch_pairs(n_pad)) return fail(RT_ERR_LIMIT, "batch boxes do not match the scan length");
+  sboxes.resize(3 * (n_pad / 64) + 3 * n_batch_pairs);
+  for (uint32_t q = 0; q < n_batch_pairs; ++q) {
+    const GroupBox &b0 = L.batches[2 * q], &b1 = L.batches[2 * q + 1];
+    float4 *dst = &sboxes[3 * (n_pad / 64) + 3 * q];
+    dst[0] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
+    dst[1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
+    dst[2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
+  }
   int rc;
-  if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(3 * (n_pad / 64))) || (rc = c->exact.reserve(n_pad)) ||
+  if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(sboxes.size())) || (rc = c->exact.reserve(n_pad)) ||
       (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
       (rc = c->orig.reserve(n_pad)) || (rc = c->inv_r_o.reserve(n)) || (rc = c->group_real.reserve(n_pad / 8)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->boxes.p, boxes.data(), 3 * (n_pad / 16) * sizeof(float4), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(c->sboxes.p, sboxes.data(), 3 * (n_pad / 64) * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->sboxes.p, sboxes.data(), sboxes.size() * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->exact.p, exact.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->geom_o.p, geom_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
@@ -1870,7 +1968,7 @@ int rt_debug_closest_hit(rt_ctx *c, const float *rays, size_t n_rays, float tmin
   }
   hipError_t e = hipMemcpy(d_rays.p, rays, 6 * n_rays * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    size_t lds = scan_lds_bytes(kMaxLdsSpheres, true);
+    size_t lds = scan_lds_bytes(kBatchSpheres, true);
     uint32_t blocks = (uint32_t)((n_rays + kBlockThreads - 1) / kBlockThreads);
     hipLaunchKernelGGL(closest_hit_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds, c->stream, scene_view(c), d_rays.p,
                        (uint32_t)n_rays, tmin, tmax, d_idx.p, d_t.p);

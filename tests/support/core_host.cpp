@@ -86,7 +86,8 @@ uint64_t core_filter_pair_mismatches(const rt_sphere *s, size_t n, const float *
 // a single ray skips.
 uint64_t core_cull_check(const rt_sphere *s, size_t n, const float *rays, size_t n_rays, uint64_t *culled,
                          uint64_t *groups) {
-  const rtcluster::Layout L = rtcluster::build_layout(s, n);
+  const size_t batch = 512;   // (the kernels' streaming batch)
+  const rtcluster::Layout L = rtcluster::build_layout(s, n, batch);
   uint64_t bad = 0, cul = 0, tot = 0;
   for (size_t r = 0; r < n_rays; r++) {
     V3 A = v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]);
@@ -97,8 +98,10 @@ uint64_t core_cull_check(const rt_sphere *s, size_t n, const float *rays, size_t
     const double inv_a = 1.0 / (double)a;
     for (size_t g = 0; g < L.boxes.size(); g++) {
       tot++;
-      // culled when the ray misses the group's box or the box of its super-group
-      if (box_pass(br, L.boxes[g]) && box_pass(br, L.supers[g / rtcluster::kSuper])) continue;
+      // culled when the ray misses the group's box, the box of its super-group or the box of its batch
+      if (box_pass(br, L.boxes[g]) && box_pass(br, L.supers[g / rtcluster::kSuper]) &&
+          box_pass(br, L.batches[g / (batch / rtcluster::kGroup)]))
+        continue;
       cul++;
       for (int k = 0; k < rtcluster::kGroup; k++) {
         const uint32_t i = L.order[g * rtcluster::kGroup + k];
@@ -117,7 +120,7 @@ uint64_t core_cull_check(const rt_sphere *s, size_t n, const float *rays, size_t
 
 // the scan order is a permutation of the list plus pads; returns 0 if so
 int core_layout_check(const rt_sphere *s, size_t n, uint32_t *n_scan, uint32_t *n_groups) {
-  const rtcluster::Layout L = rtcluster::build_layout(s, n);
+  const rtcluster::Layout L = rtcluster::build_layout(s, n, 512);
   std::vector<int> seen(n, 0);
   for (uint32_t i : L.order)
     if (i != 0xffffffffu) {
@@ -127,7 +130,8 @@ int core_layout_check(const rt_sphere *s, size_t n, uint32_t *n_scan, uint32_t *
   for (size_t i = 0; i < n; i++)
     if (seen[i] != 1) return 2;
   if (L.n_scan % 64 || L.boxes.size() * 8 != L.n_scan || L.real_in_group.size() != L.boxes.size() ||
-      L.supers.size() * rtcluster::kSuper != L.boxes.size())
+      L.supers.size() * rtcluster::kSuper != L.boxes.size() || L.batches.size() % 2 ||
+      L.batches.size() * 512 < L.n_scan)
     return 3;
   *n_scan = L.n_scan;
   *n_groups = (uint32_t)L.boxes.size();

@@ -58,11 +58,12 @@ def test_closest_hit_equals_reference_scan(renderer, rt, oracle, scene):
     assert hits > 1000
 
 
-@pytest.mark.parametrize("scene", ["small_scene", "random_scene"])
+@pytest.mark.parametrize("scene", ["small_scene", "random_scene", "streamed"])
 def test_closest_hit_close_calls(renderer, rt, oracle, scene):
-    """Rays for which 'this group is behind / beside the ray' is a close call, rays the kernel does not cull
-    at all (origin beyond 32, a zero direction component, tiny directions) and grazing rays."""
-    sc = getattr(rt, scene)()
+    """Rays for which 'this group (or, in a scene streamed in batches, this batch) is behind / beside the ray'
+    is a close call, rays the kernel does not cull at all (origin beyond 32, a zero direction component, tiny
+    directions) and grazing rays."""
+    sc = rt.random_scene(30) if scene == "streamed" else getattr(rt, scene)()
     renderer.upload(sc)
     rng = np.random.default_rng(21)
     leave = leaving_rays(rng, sc, 3000)
@@ -127,8 +128,8 @@ def test_render_equals_oracle(renderer, rt, oracle, scene, nx, ny, spp):
 
 @pytest.mark.parametrize("flags", [0, 2])
 def test_render_of_a_scene_that_streams_through_lds_in_batches(renderer, rt, oracle, flags):
-    """3,604 spheres (more than one 2,048-sphere batch): the kernel stages the list piecewise with the whole
-    workgroup in step; culled and full scan."""
+    """3,604 spheres (more than stay in LDS): the kernel stages the list in 512-sphere batches with the whole
+    workgroup in step, skipping the batches no ray of the workgroup can touch; culled and full scan."""
     sc = rt.random_scene(30)
     assert len(sc) > 2048
     renderer.upload(sc)
