@@ -30,6 +30,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -66,7 +67,10 @@ namespace {
 constexpr int kBlockThreads = 256;
 constexpr int kChunk = 8;             // spheres per unrolled filter group
 constexpr int kDrainEvery = 16;       // spheres per round of the scan (two groups)
-constexpr uint32_t kMaxLdsSpheres = 2048;  // scan positions of a scene that stays in LDS for the whole kernel
+#ifndef RT_MAX_RESIDENT
+#define RT_MAX_RESIDENT 2048
+#endif
+constexpr uint32_t kMaxLdsSpheres = RT_MAX_RESIDENT;  // scan positions of a scene that stays in LDS for the whole kernel
 constexpr uint32_t kBatchSpheres = 512;    // larger scenes: scan positions per staged batch (the LDS footprint of
                                            // a batch is that of the reference's final scene)
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
@@ -1457,6 +1461,7 @@ struct rt_ctx {
   DevBuf<double> inv_r_o;
   DevBuf<uint8_t> group_real;
   uint32_t n = 0, n_pad = 0, n_full = 0;
+  std::map<std::pair<const void *, size_t>, int> blocks_per_cu;   // resident workgroups per CU of a trace kernel variant
   float sigma0 = 0.0f, sigma1 = 0.0f;
   DevBuf<unsigned long long> counters;
   DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
@@ -1583,9 +1588,24 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
   lds += 10240;
 #endif
   const bool batched = c->n_pad > kMaxLdsSpheres, profile = (job->flags & RT_FLAG_PROFILE) != 0;
-  // persistent workgroups: enough to fill every CU at the kernel's occupancy;
-  // surplus ones find the queue empty and leave
-  const dim3 grid((unsigned)(c->num_cus * 5)), block(kBlockThreads);
+  // persistent workgroups: as many as the device holds at the chosen kernel's occupancy (registers and
+  // LDS decide: five per CU for the culled scan of a scene the size of the reference's, fewer otherwise)
+  const bool cull_scan = (job->flags & RT_FLAG_FULL_SCAN) == 0;
+  const void *kernel_fn = nullptr;
+#define RT_TRACE_FN(B, C, P) reinterpret_cast<const void *>(&trace_kernel<B, C, P>)
+  if (!batched && cull_scan && !profile) kernel_fn = RT_TRACE_FN(false, true, false);
+  if (!batched && cull_scan && profile) kernel_fn = RT_TRACE_FN(false, true, true);
+  if (!batched && !cull_scan && !profile) kernel_fn = RT_TRACE_FN(false, false, false);
+  if (!batched && !cull_scan && profile) kernel_fn = RT_TRACE_FN(false, false, true);
+  if (batched && cull_scan && !profile) kernel_fn = RT_TRACE_FN(true, true, false);
+  if (batched && cull_scan && profile) kernel_fn = RT_TRACE_FN(true, true, true);
+  if (batched && !cull_scan && !profile) kernel_fn = RT_TRACE_FN(true, false, false);
+  if (batched && !cull_scan && profile) kernel_fn = RT_TRACE_FN(true, false, true);
+#undef RT_TRACE_FN
+  int &per_cu = c->blocks_per_cu[std::make_pair(kernel_fn, lds)];   // (asked once per kernel and LDS size)
+  if (per_cu == 0) RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_fn, kBlockThreads, lds));
+  if (per_cu < 1) return fail(RT_ERR_HIP, "the trace kernel does not fit a compute unit");
+  const dim3 grid((unsigned)(c->num_cus * per_cu)), block(kBlockThreads);
 
   const int slot = (int)(c->renders % rt_ctx::kHistory);
   auto &pairs = c->trace_events[slot];
@@ -1612,18 +1632,8 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
     if (job->kernel == RT_KERNEL_WAVEFRONT) {
       if ((rc = run_wavefront_batch(c, t, npix * sb, batched, lds))) return rc;
     } else {
-      const bool cull = (job->flags & RT_FLAG_FULL_SCAN) == 0;
-#define RT_LAUNCH_TRACE(B, C, P) hipLaunchKernelGGL((trace_kernel<B, C, P>), grid, block, lds, c->stream, t)
-      if (!batched && cull && !profile) RT_LAUNCH_TRACE(false, true, false);
-      if (!batched && cull && profile) RT_LAUNCH_TRACE(false, true, true);
-      if (!batched && !cull && !profile) RT_LAUNCH_TRACE(false, false, false);
-      if (!batched && !cull && profile) RT_LAUNCH_TRACE(false, false, true);
-      if (batched && cull && !profile) RT_LAUNCH_TRACE(true, true, false);
-      if (batched && cull && profile) RT_LAUNCH_TRACE(true, true, true);
-      if (batched && !cull && !profile) RT_LAUNCH_TRACE(true, false, false);
-      if (batched && !cull && profile) RT_LAUNCH_TRACE(true, false, true);
-#undef RT_LAUNCH_TRACE
-      RT_HIP(hipGetLastError());
+      void *kernel_args[] = {&t};
+      RT_HIP(hipLaunchKernel(kernel_fn, grid, block, kernel_args, lds, c->stream));
     }
     RT_HIP(hipEventRecord(pairs[used].second, c->stream));
     ++used;
