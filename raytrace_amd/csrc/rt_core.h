@@ -399,6 +399,28 @@ RT_HD float div_f32_by(float x, float k, double inv_k) {
   return (float)div_by_widened_float((double)x, (double)k, inv_k);
 }
 
+// sqrt((double)D) for a float D > 0 (c/main.c:220 promotes the discriminant).  On the device the
+// compiler's correctly rounded square root first rescales arguments below 2^-767 and patches zero and
+// infinity afterwards; a widened positive float is never that small, so those eight instructions are
+// dropped here and the rest -- v_rsq_f64 and the compiler's own correction steps, operation for
+// operation -- is kept: the same bits for every finite argument.  An infinite D (overflowed products)
+// gives NaN here and infinity there; exact_hit's range tests fail for both roots either way.
+RT_HD double sqrt_of_widened_positive_float(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+
 // c/main.c:214-236 for one sphere.  r2 = radius*radius (a float product, as
 // the reference forms it); inv_a = 1.0 / (double)a.  On a hit inside
 // (tmin, tmax) returns true and t.
@@ -409,7 +431,7 @@ RT_HD bool exact_hit(V3 A, V3 B, float a, double inv_a, float cx, float cy, floa
   float c = dot(oc, oc) - r2;
   float D = b * b - a * c;
   if (D > 0.0f) {
-    double root = __builtin_sqrt((double)D);
+    double root = sqrt_of_widened_positive_float((double)D);
     double nb = (double)(-b), da = (double)a;
     float t0 = (float)div_by_widened_float(nb - root, da, inv_a);
     if (tmin < t0 && t0 < tmax) { t = t0; return true; }
