@@ -508,21 +508,28 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
     f.p2 = f32x2{-2.0f * ra.x, -2.0f * ra.y};
     f.p3 = f32x2{-2.0f * ra.z, rb.w};
     f.p4 = f32x2{rc.w, 0.0f};
-    f32x2 d[kChunk / 2];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const float4 *src = lds_pairs + grp * kChunk + 4 * half;
-      const float4 q[4] = {src[0], src[1], src[2], src[3]};
-      filter_two_pairs(f, q, d[2 * half], d[2 * half + 1]);
-    }
+    // A group's real spheres come first.  The second half of the groups is skipped when no pair of the
+    // pass names a group with more than four -- as in the pass over the group of the few large
+    // spheres, which every ray lists and which therefore fills a pass of its own.
+    const uint32_t real = valid ? (uint32_t)lds_real8[grp] : 0u;
+    const bool upper_half = __ballot(real > (uint32_t)(kChunk / 2)) != 0ull;
+    f32x2 d[kChunk / 2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
     // first word of this lane's entries: owner | scan position of the group's first sphere
     const uint32_t word0 = (owner << 16) | (base + grp * kChunk);
     const unsigned long long valid_mask = __ballot(valid);   // (a scalar AND per sphere instead of a vector select)
     // Eight compares into eight scalar masks, OR-ed on the scalar unit, one branch
     // for the whole pass: no branch waits on a vector compare of its own.
-    unsigned long long m[kChunk];
+    unsigned long long m[kChunk] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #pragma unroll
-    for (int u = 0; u < kChunk; ++u) m[u] = __ballot(d[u >> 1][u & 1] > 0.0f) & valid_mask;
+    for (int half = 0; half < 2; ++half) {
+      if (half == 0 || upper_half) {
+        const float4 *src = lds_pairs + grp * kChunk + 4 * half;
+        const float4 q[4] = {src[0], src[1], src[2], src[3]};
+        filter_two_pairs(f, q, d[2 * half], d[2 * half + 1]);
+#pragma unroll
+        for (int u = 4 * half; u < 4 * half + 4; ++u) m[u] = __ballot(d[u >> 1][u & 1] > 0.0f) & valid_mask;
+      }
+    }
     const unsigned long long any = ((m[0] | m[1]) | (m[2] | m[3])) | ((m[4] | m[5]) | (m[6] | m[7]));
     if (any != 0ull) {
       asm volatile("");  // (keeps the block a branch target; without it the nested ifs are merged)
@@ -555,7 +562,7 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
         }
       }
     }
-    if (valid) h.lane_tests += lds_real8[grp];
+    h.lane_tests += real;
     e0 += width;
     width = 64u;
   }
