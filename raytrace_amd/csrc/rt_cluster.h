@@ -55,6 +55,7 @@ struct Layout {
   std::vector<rtcore::GroupBox> supers; // one per kSuper consecutive groups: the box around their boxes
   std::vector<rtcore::GroupBox> batches; // one per batch_spheres scan positions (an even number of them): the box around its super-groups
   std::vector<uint8_t> real_in_group; // real (non-pad) spheres per group
+  uint32_t n_always_groups = 0;       // the first so many groups are the "always scan" ones; no box in `supers` covers them
   uint32_t n_scan = 0;                // = order.size(), a multiple of 2*kSuper*kGroup (a pair of super-groups)
   float sigma0 = 0.0f, sigma1 = 0.0f; // per-ray growth of the half extents: 1 + sigma0 + sigma1 |A|^2 (rt_core.h)
 };
@@ -157,11 +158,12 @@ inline Layout build_layout(const rt_sphere *s, size_t n, size_t batch_spheres) {
   for (size_t k = 0; k < regular.size(); k += kGroup)
     emit_group(&regular[k], std::min<size_t>(kGroup, regular.size() - k), false);
   while (L.boxes.size() % (2 * kSuper)) emit_group(nullptr, 0, false);   // whole pairs of super-groups
-  // the box around boxes [first, last) of `from` ("always" if one of them is, "never" if all are)
-  auto box_around = [&](const std::vector<rtcore::GroupBox> &from, size_t first, size_t last) {
+  // the box around boxes [first, last) of `from`, those below index `skip_below` left out: "never" if
+  // none of them is a real box, "always" if one of them is
+  auto box_around = [&](const std::vector<rtcore::GroupBox> &from, size_t first, size_t last, size_t skip_below) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     bool always = false, any = false;
-    for (size_t g = first; g < last && g < from.size(); ++g) {
+    for (size_t g = std::max(first, skip_below); g < last && g < from.size(); ++g) {
       const rtcore::GroupBox &b = from[g];
       if (b.hx > 1.0e29f) always = true;
       if (b.hx > 1.0e29f || b.hx < 0.0f) continue;
@@ -178,9 +180,19 @@ inline Layout build_layout(const rt_sphere *s, size_t n, size_t batch_spheres) {
     }
     return widened_box(lo, hi);
   };
-  for (size_t g0 = 0; g0 < L.boxes.size(); g0 += kSuper) L.supers.push_back(box_around(L.boxes, g0, g0 + kSuper));
+  // The kernels put the first "always" groups (up to kSuper of them: one list's worth) on every ray's
+  // list without a test, so the box of their super-group is the box around its other groups; a batch
+  // that holds such a group is staged for every ray all the same.  Further "always" groups, if a scene
+  // has that many large spheres, make their super-group an "always" one.
+  L.n_always_groups = (uint32_t)std::min<size_t>((large.size() + kGroup - 1) / kGroup, (size_t)kSuper);
+  std::vector<rtcore::GroupBox> supers_or_always;
+  for (size_t g0 = 0; g0 < L.boxes.size(); g0 += kSuper) {
+    L.supers.push_back(box_around(L.boxes, g0, g0 + kSuper, L.n_always_groups));
+    supers_or_always.push_back(box_around(L.boxes, g0, g0 + kSuper, 0));
+  }
   const size_t supers_per_batch = batch_spheres / (kSuper * kGroup);
-  for (size_t q0 = 0; q0 < L.supers.size(); q0 += supers_per_batch) L.batches.push_back(box_around(L.supers, q0, q0 + supers_per_batch));
+  for (size_t q0 = 0; q0 < L.supers.size(); q0 += supers_per_batch)
+    L.batches.push_back(box_around(supers_or_always, q0, q0 + supers_per_batch, 0));
   if (L.batches.size() % 2) L.batches.push_back(rtcore::GroupBox{0.0f, 0.0f, 0.0f, -1.0e30f, -1.0e30f, -1.0e30f});
   L.n_scan = (uint32_t)L.order.size();
   if (h_min < 1e299) {   // (else there is nothing to cull)

@@ -93,6 +93,8 @@ struct DeviceScene {
   float sigma0, sigma1;   // per-ray growth of the group boxes (rt_core.h, rt_cluster.h)
   uint32_t n_full;        // scan positions up to the last real sphere, rounded up to a round (16): what a
                           // scan without culling has to visit (the rest is padding)
+  uint32_t n_always_groups;   // the first so many groups go on every ray's list untested; their entries in
+                              // `boxes` say "never", and `sboxes` are the boxes around the other groups
 };
 
 // The boxes of the batches of a streamed scene follow the super-group boxes in the same array: 3 entries
@@ -637,6 +639,13 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     list_group(m0, mine0, i0 >> 3);
     list_group(m1, mine1, (i0 >> 3) + 1u);
   };
+  // the groups every ray scans (the scene's few large spheres): on every live lane's list, untested
+  // (the lanes that list every group anyway get them from the rounds below)
+  // (at most kSuper of them, 64 entries each: the list, empty at this point, holds them)
+  static_assert(kPairListCap >= 64u * rtcluster::kSuper, "the untested groups must fit the list");
+  if (base == 0u) {
+    for (uint32_t g = 0; g < sc.n_always_groups; ++g) list_group(live_mask & ~all_mask, alive && !uncullable, g);
+  }
   // Super-groups first, all of them in one tight loop (the boxes of a pair of super-groups, 64 spheres,
   // in one packed evaluation; two pairs per trip so that the reads of one overlap the arithmetic of the
   // other and no register is copied): a bit per super-group some lane's ray can touch.  A batch has at
@@ -1467,7 +1476,7 @@ struct rt_ctx {
   DevBuf<uint32_t> orig;
   DevBuf<double> inv_r_o;
   DevBuf<uint8_t> group_real;
-  uint32_t n = 0, n_pad = 0, n_full = 0;
+  uint32_t n = 0, n_pad = 0, n_full = 0, n_always_groups = 0;
   std::map<std::pair<const void *, size_t>, int> blocks_per_cu;   // resident workgroups per CU of a trace kernel variant
   float sigma0 = 0.0f, sigma1 = 0.0f;
   DevBuf<unsigned long long> counters;
@@ -1504,7 +1513,7 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full, c->n_always_groups};
 }
 
 size_t scan_lds_bytes(uint32_t entries, bool cull) {
@@ -1831,8 +1840,10 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     filter[p2] = make_float4(fs[p2].cx, fs[p2 + 1].cx, fs[p2].cy, fs[p2 + 1].cy);
     filter[p2 + 1] = make_float4(fs[p2].cz, fs[p2 + 1].cz, fs[p2].kprime, fs[p2 + 1].kprime);
   }
+  const GroupBox never{0.0f, 0.0f, 0.0f, -1.0e30f, -1.0e30f, -1.0e30f};
   for (uint32_t g = 0; g < n_pad / 8; g += 2) {
-    const GroupBox &b0 = L.boxes[g], &b1 = L.boxes[g + 1];
+    // (the groups every ray scans are listed without a test: the box tests must not list them again)
+    const GroupBox &b0 = g < L.n_always_groups ? never : L.boxes[g], &b1 = g + 1 < L.n_always_groups ? never : L.boxes[g + 1];
     boxes[3 * (g / 2)] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
     boxes[3 * (g / 2) + 1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
     boxes[3 * (g / 2) + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
@@ -1871,6 +1882,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->n = (uint32_t)n;
   c->n_pad = n_pad;
+  c->n_always_groups = L.n_always_groups;
   c->sigma0 = L.sigma0;
   c->sigma1 = L.sigma1;
   uint32_t last_real = 0;

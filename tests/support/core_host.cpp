@@ -96,7 +96,7 @@ uint64_t core_cull_check(const rt_sphere *s, size_t n, const float *rays, size_t
     const BoxRay br = make_box_ray(A, B, L.sigma0, L.sigma1);
     const float a = dot(B, B);
     const double inv_a = 1.0 / (double)a;
-    for (size_t g = 0; g < L.boxes.size(); g++) {
+    for (size_t g = L.n_always_groups; g < L.boxes.size(); g++) {   // (the first groups are scanned for every ray)
       tot++;
       // culled when the ray misses the group's box, the box of its super-group or the box of its batch
       if (box_pass(br, L.boxes[g]) && box_pass(br, L.supers[g / rtcluster::kSuper]) &&

@@ -37,9 +37,17 @@ def test_filter_has_no_false_negatives(core, rt, builder):
     assert passed.value < 1.35 * pos.value + 3 * len(rays)   # ... and the filter is not much looser
 
 
-@pytest.mark.parametrize("builder", ["small_scene", "random_scene", "glass_scene", "dense"])
+def many_large_spheres(rt):
+    """The final scene with 45 of its small spheres blown up: more large spheres than the kernels list untested."""
+    sc = rt.random_scene().copy()
+    sc["radius"][10:460:10] *= 6.0
+    return sc
+
+
+@pytest.mark.parametrize("builder", ["small_scene", "random_scene", "glass_scene", "dense", "many_large"])
 def test_group_culling_never_hides_a_hit(core, rt, builder):
-    sc = rt.random_scene(100)[::7][:4000] if builder == "dense" else getattr(rt, builder)()
+    sc = (rt.random_scene(100)[::7][:4000] if builder == "dense" else many_large_spheres(rt) if builder == "many_large"
+          else getattr(rt, builder)())
     n_scan, n_groups = C.c_uint32(), C.c_uint32()
     assert core.core_layout_check(vp(sc), C.c_size_t(len(sc)), C.byref(n_scan), C.byref(n_groups)) == 0
     assert n_scan.value >= len(sc) and n_scan.value < len(sc) + 64 + len(sc) // 4

@@ -158,6 +158,19 @@ def test_degenerate_spheres_and_rays_do_not_break_the_scan(renderer, rt, oracle)
     assert_parity(got, want)
 
 
+def test_more_large_spheres_than_are_listed_untested(renderer, rt, oracle):
+    """45 spheres far larger than the median: the first four groups of them go on every ray's list untested,
+    the others ride on box tests that always pass."""
+    sc = rt.random_scene().copy()
+    sc["radius"][10:460:10] *= 6.0
+    renderer.upload(sc)
+    nx, ny, spp = 120, 68, 4
+    cam = rt.camera_default(nx, ny)
+    got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=12))
+    want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=12, host_threads=16)
+    assert_parity(got, want)
+
+
 @pytest.mark.parametrize("flags", [0, 2])
 def test_nested_shells_overflow_the_candidate_lists(renderer, rt, oracle, flags):
     """48 concentric spheres of nearly the same radius: every ray aimed at the centre passes the filter for
