@@ -271,10 +271,12 @@ def test_full_size_properties(renderer, rt):
     assert np.isfinite(out["linear"]).all()
 
 
-@pytest.mark.parametrize("scene,nx,ny,spp", [("small_scene", 200, 100, 8), ("random_scene", 320, 180, 8), ("glass_scene", 160, 90, 16)])
+@pytest.mark.parametrize("scene,nx,ny,spp", [("small_scene", 200, 100, 8), ("random_scene", 320, 180, 8), ("glass_scene", 160, 90, 16),
+                                             ("streamed", 96, 54, 2)])
 def test_wavefront_variant_is_bit_identical_to_the_megakernel(renderer, rt, scene, nx, ny, spp):
-    """The material-sorted wavefront stages share the arithmetic, so every output must match exactly."""
-    renderer.upload(getattr(rt, scene)())
+    """The material-sorted wavefront stages share the arithmetic, so every output must match exactly
+    ("streamed": 3,604 spheres, staged through LDS in batches by both variants)."""
+    renderer.upload(rt.random_scene(30) if scene == "streamed" else getattr(rt, scene)())
     cam = rt.camera_default(nx, ny)
     mega = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=3, kernel=rt.KERNEL_MEGA))
     renderer.counters(reset=True)
