@@ -84,6 +84,30 @@ def test_closest_hit_close_calls(renderer, rt, oracle, scene):
     assert hits > 1000
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 63, 64, 65, 500, 512, 513, 2040, 2048, 2049, 2600])
+def test_closest_hit_for_every_list_length_class(renderer, rt, oracle, n):
+    """List lengths around the group (8), super-group pair (64), batch (512) and LDS-resident (2048) limits:
+    padding, partial groups and the switch to streaming must not change the hit."""
+    full = rt.random_scene(30)
+    rng = np.random.default_rng(100 + n)
+    sc = full[np.sort(rng.choice(len(full), size=n, replace=False))].copy()
+    renderer.upload(sc)
+    rays = np.concatenate([random_rays(rng, 500, sc), leaving_rays(rng, sc, 300)]).astype(np.float32)
+    idx, t = renderer.closest_hit(rays)
+    osc = as_oracle_scene(sc)
+    for i, r in enumerate(rays):
+        oi, ot, _, _ = oracle.hit_scene(osc, r[:3], r[3:])
+        assert oi == idx[i], (n, i, oi, idx[i])
+        if oi >= 0:
+            assert ot.tobytes() == t[i].tobytes()
+    # and a small render through the trace kernel proper (the debug entry always streams)
+    nx, ny, spp = 64, 36, 2
+    cam = rt.camera_default(nx, ny)
+    got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=n))
+    want = oracle.render_det(cam.as_array(), osc, nx, ny, spp, seed=n, host_threads=16)
+    assert_parity(got, want)
+
+
 def test_closest_hit_dense_scene_batches(renderer, rt, oracle):
     """40,004 spheres: the scan streams LDS batches; ties keep the lowest index."""
     sc = rt.random_scene(100)
