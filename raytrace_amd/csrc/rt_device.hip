@@ -619,26 +619,6 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
       w.pcnt += (uint32_t)__popcll(m);
     }
   };
-  // one round: the two boxes in q against every lane's ray
-  auto round = [&](const float4 (&q)[3], uint32_t i0) {
-    bool pass[2];
-    box_pair(br, q, pass);
-#if RT_EXP == 13
-    {
-      bool pass2[2];
-      box_pair(br, q, pass2);
-      asm volatile("" ::"s"(__ballot(pass2[0])), "s"(__ballot(pass2[1])));
-    }
-#endif
-    const bool mine0 = (pass[0] && alive) || uncullable, mine1 = (pass[1] && alive) || uncullable;
-    const unsigned long long m0 = (__ballot(pass[0]) & live_mask) | all_mask, m1 = (__ballot(pass[1]) & live_mask) | all_mask;
-    tests += 2u;
-    h.own_groups += (mine0 ? 1u : 0u) + (mine1 ? 1u : 0u);
-    h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
-    if (w.pcnt > kPairListFlush) filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);
-    list_group(m0, mine0, i0 >> 3);
-    list_group(m1, mine1, (i0 >> 3) + 1u);
-  };
   // the groups every ray scans (the scene's few large spheres): on every live lane's list, untested
   // (the lanes that list every group anyway get them from the rounds below)
   // (at most kSuper of them, 64 entries each: the list, empty at this point, holds them)
@@ -675,16 +655,54 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     }
     tests += 2u * n_pairs;
   }
-  // then the two rounds (four group boxes) of every super-group that was touched
-  while (touched != 0ull) {
-    const uint32_t sg = (uint32_t)__builtin_ctzll(touched);
+  // then the two rounds (four group boxes) of every super-group that was touched, the boxes of a round
+  // read while the round before it is worked on (two register sets, no copies)
+  if (touched != 0ull) {
+    auto load_round = [&](float4 (&q)[3], uint32_t first) {
+      q[0] = lds_boxes[first];
+      q[1] = lds_boxes[first + 1u];
+      q[2] = lds_boxes[first + 2u];
+    };
+    // one round: the two boxes in q against every lane's ray.  Should the pair list have to be filtered
+    // first, the boxes read ahead (`ahead`, from entry `ahead_first`) are read again afterwards rather
+    // than kept in registers across the filter pass.
+    auto round2 = [&](const float4 (&q)[3], uint32_t i0, float4 (&ahead)[3], uint32_t ahead_first) {
+      bool pass[2];
+      box_pair(br, q, pass);
+#if RT_EXP == 13
+      {
+        bool pass2[2];
+        box_pair(br, q, pass2);
+        asm volatile("" ::"s"(__ballot(pass2[0])), "s"(__ballot(pass2[1])));
+      }
+#endif
+      const bool mine0 = (pass[0] && alive) || uncullable, mine1 = (pass[1] && alive) || uncullable;
+      const unsigned long long m0 = (__ballot(pass[0]) & live_mask) | all_mask, m1 = (__ballot(pass[1]) & live_mask) | all_mask;
+      tests += 2u;
+      h.own_groups += (mine0 ? 1u : 0u) + (mine1 ? 1u : 0u);
+      h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
+      if (w.pcnt > kPairListFlush) {
+        filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);
+        load_round(ahead, ahead_first);
+      }
+      list_group(m0, mine0, i0 >> 3);
+      list_group(m1, mine1, (i0 >> 3) + 1u);
+    };
+    uint32_t sg = (uint32_t)__builtin_ctzll(touched);
     touched &= touched - 1ull;
-    const uint32_t j0 = sg * (2u * kDrainEvery);
-    const uint32_t ib = 3u * (j0 >> 4);
-#pragma unroll 1
-    for (uint32_t r = 0; r < 2u; ++r) {
-      const float4 q[3] = {lds_boxes[ib + 3u * r], lds_boxes[ib + 3u * r + 1], lds_boxes[ib + 3u * r + 2]};
-      round(q, j0 + kDrainEvery * r);
+    float4 qa[3], qb[3];
+    load_round(qa, 6u * sg);   // (a super-group's two rounds are six consecutive entries)
+    for (;;) {
+      const uint32_t j0 = sg * (2u * kDrainEvery);
+      load_round(qb, 6u * sg + 3u);
+      round2(qa, j0, qb, 6u * sg + 3u);
+      const bool more = touched != 0ull;
+      const uint32_t next_sg = more ? (uint32_t)__builtin_ctzll(touched) : sg;   // (at the end: a read for nothing)
+      touched &= touched - 1ull;
+      load_round(qa, 6u * next_sg);
+      round2(qb, j0 + kDrainEvery, qa, 6u * next_sg);
+      if (!more) break;
+      sg = next_sg;
     }
   }
   filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);   // (the pairs name groups of this batch)
