@@ -224,13 +224,20 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
     const uint32_t e = e0 + w.lane;
     if (e < w.wcnt) {
       const uint32_t entry = *(lds_u32 *)(uintptr_t)(w.wlist_off + (e << 2));
-      const uint32_t owner = entry >> 16, pos = entry & 0xffffu;
+      const uint32_t owner = entry >> 16;
+      // byte offsets of the sphere's entries: (entry & 0xffff) << 4 and << 2, one instruction each with
+      // the shift count in a scalar register (the compiler's form of the same instruction keeps the
+      // count in a vector register for the whole kernel)
+      uint32_t off16, off4;
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(off16) : "s"(4u), "v"(entry));
       const float4 ra = w.rays[3 * owner], rb = w.rays[3 * owner + 1];
       const double inv_a = *reinterpret_cast<const double *>(&w.rays[3 * owner + 2]);
-      const float4 ex = sc.exact[pos];
+      const float4 ex = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.exact) + off16);
       float t;
       if (exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, inv_a, ex.x, ex.y, ex.z, ex.w, w.tmin, kFltMax, t)) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | sc.orig[pos];
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(off4) : "s"(2u), "v"(entry));
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) |
+                                       *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sc.orig) + off4);
         atomicMin(&w.best[owner], key);
       }
     }
@@ -742,7 +749,13 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   lds.rays[3 * tid] = make_float4(A.x, A.y, A.z, a);
   lds.rays[3 * tid + 1] = make_float4(B.x, B.y, B.z, f.na);
   lds.rays[3 * tid + 2] = make_float4(__int_as_float(__double2loint(inv_a)), __int_as_float(__double2hiint(inv_a)), f.ab, f.naaa);
-  lds.best[tid] = (unsigned long long)__float_as_uint(tmax) << 32;
+  {
+    // (made here on every call: as a loop invariant the 64-bit constant would sit in two vector
+    // registers for the whole kernel)
+    uint32_t no_hit_hi = __float_as_uint(tmax), no_hit_lo = 0u;
+    asm volatile("" : "+v"(no_hit_hi), "+v"(no_hit_lo));
+    lds.best[tid] = ((unsigned long long)no_hit_hi << 32) | no_hit_lo;
+  }
   if (kBatched) {
     // Which batches to stage: those whose box some ray of the workgroup can touch.  Every lane tests
     // its ray against every batch box (two per packed evaluation, the boxes read through the scalar
@@ -951,7 +964,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
         n_iter++;
         n_live += (unsigned long long)__popcll(__ballot(alive));
       }
-      HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u, 0ull};
+      HitState h{0.0f, -1, 0u, 0u, 0u, 0u, 0u, 0ull};   // (closest is read only where index >= 0)
       closest_hit_scene<kBatched, kCull, kProfile>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
       if (kProfile) {
         c2 = tick();
@@ -1015,7 +1028,11 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
       const rt_job &jb = geo.job;
       if (pool_next == pool_end) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)), kChunkItems);
+        if (lane == 0) {
+          unsigned int take = kChunkItems;
+          asm volatile("" : "+v"(take));   // (not a loop invariant held in a vector register)
+          base = atomicAdd(kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)), take);
+        }
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= geo.total_items) {
           exhausted = true;
