@@ -206,15 +206,15 @@ def main():
         ldt = time.perf_counter() - t0
         lc = r.counters()
         l_ms = float(np.mean([r.trace_ms(back) for back in range(args.steps)]))
-        l_ach = FLOP_PER_TEST * lc["tests"] / args.steps / (l_ms * 1e-3) / 1e12
+        l_ach = FLOP_PER_TEST * (lc["sphere_tests"] + lc["box_tests"]) / args.steps / (l_ms * 1e-3) / 1e12
         linear = {"value": total_paths_per_step * args.steps / ldt, "unit": "camera paths/s", "ms_per_step": ldt / args.steps * 1e3,
                   "roofline": {"bound": "fp32_valu", "achieved": l_ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": l_ach / FP32_PEAK_TFLOPS, "kernel": "trace_kernel (RT_FLAG_FULL_SCAN)",
-                               "kernel_ms_avg": l_ms, "tests_per_path": lc["tests"] / max(1, lc["paths"])}}
+                               "kernel_ms_avg": l_ms, "tests_per_path": (lc["sphere_tests"] + lc["box_tests"]) / max(1, lc["paths"])}}
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        tests_per_launch = counters["tests"] / args.steps
+        tests_per_launch = (counters["sphere_tests"] + counters["box_tests"]) / args.steps
         achieved = FLOP_PER_TEST * tests_per_launch / (k_ms * 1e-3) / 1e12
         # the counter passes were collected on this workload's 64-spp full frame; scaled to this rank's share
         traffic, traffic_source, counters_pmc = (hbm_traffic("full" if args.full_scan else "culled")
@@ -245,7 +245,7 @@ def main():
                          "kernel_ms_avg": k_ms, "render_ms_avg": float(np.mean(launch_ms)),
                          "flop_per_test": FLOP_PER_TEST,
                          "tests_per_launch": tests_per_launch,
-                         "tests_per_path": counters["tests"] / max(1, counters["paths"]),
+                         "tests_per_path": (counters["sphere_tests"] + counters["box_tests"]) / max(1, counters["paths"]),
                          "segments_per_path": counters["segments"] / max(1, counters["paths"]),
                          "exact_evaluations_per_segment": counters["candidates"] / max(1, counters["segments"]),
                          "rank0_paths_per_launch": paths_per_step_rank},

@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 1
+/* 2: rt_job.sample0 and RT_FLAG_PROGRESSIVE; rt_counters.tests split into sphere_tests and box_tests;
+ *    the unit-level rt_debug_filter / rt_debug_box_pass / rt_debug_arith */
+#define RT_AMD_ABI_VERSION 2
 
 enum {
   RT_OK = 0,
@@ -77,6 +79,9 @@ typedef struct {
   uint32_t seed;            /* seed of the counter generator                    */
   uint32_t kernel;          /* RT_KERNEL_*                                      */
   uint32_t flags;           /* RT_FLAG_* or 0                                   */
+  uint32_t sample0;         /* index of the first sample this call renders: 0, or, with
+                               RT_FLAG_PROGRESSIVE, the number of samples the context's
+                               running sums already hold                        */
 } rt_job;
 
 /* also fill the cycle and lane-occupancy counters of rt_counters (slower) */
@@ -85,12 +90,23 @@ typedef struct {
  * whose bounding sphere no ray of the wave can touch; same image either way */
 #define RT_FLAG_FULL_SCAN 2u
 
+/* Keep the per-pixel running sums of this render in the context, and, when sample0 > 0, continue
+ * them: the call renders samples [sample0, sample0 + nsamples) of every pixel and its outputs are the
+ * mean over all sample0 + nsamples samples, added in sample order (c/main.c:462-469) -- so k calls of m
+ * samples give the bytes of one call of k*m samples.  A call with sample0 > 0 must follow, on the same
+ * context, a progressive call with the same scene, camera, image geometry, seed, depth and tmin whose
+ * samples ended at sample0; anything else is RT_ERR_ARG.  This is what a viewer that re-renders on a
+ * camera change and refines while the camera rests needs (rs/src/gui.rs:164-172, 340-357). */
+#define RT_FLAG_PROGRESSIVE 4u
+
 /* Device-side event counts accumulated by the kernels since the last reset. */
 typedef struct {
   uint64_t paths;           /* camera paths finished                            */
   uint64_t segments;        /* closest-hit scans (calls of hit_scene, c/main.c:264) */
-  uint64_t tests;           /* ray-sphere filter tests executed in those scans (group bounds included) */
-  uint64_t candidates;      /* tests that went on to the exact evaluation       */
+  uint64_t sphere_tests;    /* ray-sphere tests executed in those scans: one per (ray, real sphere) put through the
+                               discriminant filter (the test of c/main.c:216-221); a full scan runs segments * n */
+  uint64_t box_tests;       /* ray-box tests of the culled scan: super-group, group and batch boxes, one per (ray, box) */
+  uint64_t candidates;      /* sphere tests that went on to the exact evaluation */
   /* the rest only with RT_FLAG_PROFILE, summed over waves */
   uint64_t wave_iterations;      /* bounce-loop iterations                      */
   uint64_t live_lane_iterations; /* lanes with a live path in those iterations  */
@@ -157,6 +173,35 @@ int rt_debug_closest_hit(rt_ctx *ctx, const float *rays, size_t n_rays,
  * device computes them (host pointer, doubles) */
 int rt_debug_uniforms(rt_ctx *ctx, uint32_t seed, uint32_t pixel,
                       uint32_t sample, size_t n, double *out);
+
+
+/* The kernels evaluate the conservative discriminant filter, the group box test and a few divisions and
+ * square roots with hand-scheduled packed instructions.  These entry points run exactly those device
+ * routines on caller-supplied operands (host pointers) so that tests can compare them value for value
+ * with the plain statement of the same arithmetic (csrc/rt_core.h compiled for the host), which follows
+ * c/main.c:216-222.
+ *
+ * rt_debug_filter: the filter discriminant of every (ray, sphere) pair.  rays: 6 floats each (A, B);
+ * spheres: 4 floats each (centre, radius), n_spheres a multiple of 8.  df_four / df_two: n_rays *
+ * n_spheres floats each (ray-major), from the eight-sphere and the four-sphere routine. */
+int rt_debug_filter(rt_ctx *ctx, const float *rays, size_t n_rays, const float *spheres, size_t n_spheres,
+                    float *df_four, float *df_two);
+/* rt_debug_box_pass: boxes: 6 floats each (centre, half extents), n_boxes even.  pass_vec / pass_sca:
+ * n_rays * n_boxes bytes (0/1) from the routine that reads boxes from vector and from scalar registers;
+ * box_ray: 9 floats per ray, the per-ray coefficients as the device formed them (its reciprocal is not
+ * the host's). */
+int rt_debug_box_pass(rt_ctx *ctx, const float *rays, size_t n_rays, const float *boxes, size_t n_boxes,
+                      float sigma0, float sigma1, uint8_t *pass_vec, uint8_t *pass_sca, float *box_ray);
+/* rt_debug_arith: out[i] = op(a[i], b[i]) in doubles (floats are widened exactly):
+ *   RT_ARITH_SQRT_WIDENED   sqrt((double)(float)a)                        (c/main.c:222)
+ *   RT_ARITH_DIV_WIDENED    a / (double)(float)b through the reciprocal   (c/main.c:223, 231)
+ *   RT_ARITH_DIV_F32_BY     (float)a / (float)b through the reciprocal    (c/main.c:229, 465-466)
+ *   RT_ARITH_RCP_NARROWED   (float)(1.0 / (double)(float)a)               (c/vec.c:45)
+ *   RT_ARITH_UNIT_FLOAT     (float) of the draw with 31-bit integer a     (c/rand.c:15, c/vec.c:68)
+ *   RT_ARITH_UNIT_DOUBLE    the same draw as a double                     (c/rand.c:15) */
+enum { RT_ARITH_SQRT_WIDENED = 0, RT_ARITH_DIV_WIDENED = 1, RT_ARITH_DIV_F32_BY = 2, RT_ARITH_RCP_NARROWED = 3,
+       RT_ARITH_UNIT_FLOAT = 4, RT_ARITH_UNIT_DOUBLE = 5 };
+int rt_debug_arith(rt_ctx *ctx, int op, const double *a, const double *b, size_t n, double *out);
 
 #ifdef __cplusplus
 }

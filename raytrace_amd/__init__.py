@@ -11,11 +11,12 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from ._native import (DIELECTRIC, KERNEL_MEGA, KERNEL_WAVEFRONT, MATTE, METAL, SCENE_DENSE, SCENE_FINAL, SCENE_GLASS,
-                      SCENE_SMALL, SCENE_TRIVIAL, SPHERE_DTYPE, RtCamera, RtError, RtJob)
+from ._native import (DIELECTRIC, FLAG_FULL_SCAN, FLAG_PROFILE, FLAG_PROGRESSIVE, KERNEL_MEGA, KERNEL_WAVEFRONT, MATTE, METAL,
+                      SCENE_DENSE, SCENE_FINAL, SCENE_GLASS, SCENE_SMALL, SCENE_TRIVIAL, SPHERE_DTYPE,
+                      RtCamera, RtError, RtJob)
 
 __all__ = ["camera_new", "camera_default", "small_scene", "trivial_scene", "random_scene", "glass_scene",
-           "build_scene", "Job", "Renderer", "raytrace", "write_ppm", "device_count", "RtError", "SPHERE_DTYPE"]
+           "build_scene", "Job", "Renderer", "RenderService", "raytrace", "write_ppm", "device_count", "RtError", "SPHERE_DTYPE"]
 
 
 def _f3(v):
@@ -88,10 +89,10 @@ def device_count():
 
 
 def Job(nx, ny, nsamples, max_depth=50, seed=0, row0=0, tile_rows=None, tile_stride=None, n_tiles=1,
-        kernel=KERNEL_MEGA, tmin=np.float32(0.001), flags=0):
+        kernel=KERNEL_MEGA, tmin=np.float32(0.001), flags=0, sample0=0):
     tile_rows = (ny - row0) if tile_rows is None else tile_rows
     tile_stride = tile_rows if tile_stride is None else tile_stride
-    return RtJob(nx, ny, row0, tile_rows, tile_stride, n_tiles, nsamples, max_depth, float(tmin), seed, kernel, flags)
+    return RtJob(nx, ny, row0, tile_rows, tile_stride, n_tiles, nsamples, max_depth, float(tmin), seed, kernel, flags, sample0)
 
 
 def job_rows(job):
@@ -195,6 +196,35 @@ class Renderer:
         N.check(N.device.rt_debug_uniforms(self._h, seed, pixel, sample, n, out.ctypes.data), "rt_debug_uniforms")
         return out
 
+    def debug_filter(self, rays, spheres4):
+        """Filter discriminants of every (ray, sphere) pair from the device's two packed routines."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        sp = np.ascontiguousarray(spheres4, np.float32).reshape(-1, 4)
+        four = np.zeros((len(rays), len(sp)), np.float32)
+        two = np.zeros_like(four)
+        N.check(N.device.rt_debug_filter(self._h, rays.ctypes.data, len(rays), sp.ctypes.data, len(sp), four.ctypes.data,
+                                         two.ctypes.data), "rt_debug_filter")
+        return four, two
+
+    def debug_box_pass(self, rays, boxes6, sigma0, sigma1):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        bx = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+        vec = np.zeros((len(rays), len(bx)), np.uint8)
+        sca = np.zeros_like(vec)
+        box_ray = np.zeros((len(rays), 9), np.float32)
+        N.check(N.device.rt_debug_box_pass(self._h, rays.ctypes.data, len(rays), bx.ctypes.data, len(bx), float(sigma0),
+                                           float(sigma1), vec.ctypes.data, sca.ctypes.data, box_ray.ctypes.data),
+                "rt_debug_box_pass")
+        return vec, sca, box_ray
+
+    def debug_arith(self, op, a, b=None):
+        a = np.ascontiguousarray(a, np.float64)
+        b = None if b is None else np.ascontiguousarray(b, np.float64)
+        out = np.zeros(len(a), np.float64)
+        N.check(N.device.rt_debug_arith(self._h, op, a.ctypes.data, None if b is None else b.ctypes.data, len(a),
+                                        out.ctypes.data), "rt_debug_arith")
+        return out
+
 
 def raytrace(cam, spheres, nx, ny, nsamples, n_devices=1, max_depth=50, seed=0, tile_rows=8, kernel=KERNEL_MEGA,
              device_ids=None):
@@ -207,9 +237,55 @@ def raytrace(cam, spheres, nx, ny, nsamples, n_devices=1, max_depth=50, seed=0, 
         ids = (C.c_int * len(device_ids))(*device_ids)
     opts = N.RthRenderOpts(nx, ny, nsamples, max_depth, seed, tile_rows, kernel, n_devices, ids)
     ms = C.c_float()
-    N.check(N.host.rth_raytrace(C.byref(cam), s.ctypes.data, len(s), C.byref(opts), img.ctypes.data, C.byref(ms)),
-            "rth_raytrace")
+    rc = N.host.rth_raytrace(C.byref(cam), s.ctypes.data, len(s), C.byref(opts), img.ctypes.data, C.byref(ms))
+    if rc != 0:
+        raise RuntimeError(f"rth_raytrace: error {rc}: {N.host.rth_last_error().decode()}")
     return img, ms.value
+
+
+class RenderService:
+    """rth_service_* of host/rt_host.h: a resident worker that re-renders on a new camera and refines
+    progressively (the worker of rs/src/gui.rs:164-172 with the scene kept on the GPU)."""
+
+    def __init__(self, spheres, device=0):
+        s = np.ascontiguousarray(spheres)
+        h = C.c_void_p()
+        rc = N.host.rth_service_start(device, s.ctypes.data, len(s), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"rth_service_start: error {rc}: {N.host.rth_last_error().decode()}")
+        self._h = h
+
+    def submit(self, cam, nx, ny, pass_samples, target_samples, max_depth=50, seed=0):
+        rq = N.RthServiceRequest(nx, ny, pass_samples, target_samples, max_depth, seed)
+        rid = N.host.rth_service_submit(self._h, C.byref(cam), C.byref(rq))
+        if rid == 0:
+            raise ValueError("bad request")
+        return rid
+
+    def wait(self, rid, min_samples):
+        rc = N.host.rth_service_wait(self._h, rid, min_samples)
+        if rc != 0:
+            raise RuntimeError(f"rth_service_wait: error {rc}: {N.host.rth_last_error().decode()}")
+
+    def latest(self, nx, ny):
+        img = np.zeros((ny, nx, 3), np.uint8)
+        rid, samples, gx, gy = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = N.host.rth_service_latest(self._h, img.ctypes.data, img.nbytes, C.byref(rid), C.byref(samples), C.byref(gx),
+                                       C.byref(gy))
+        if rc != 0:
+            return None
+        return {"rgb8": img[:gy.value, :gx.value] if (gx.value, gy.value) == (nx, ny) else None, "id": rid.value,
+                "samples": samples.value, "nx": gx.value, "ny": gy.value}
+
+    def stats(self):
+        u, p = C.c_uint64(), C.c_uint64()
+        N.host.rth_service_stats(self._h, C.byref(u), C.byref(p))
+        return {"uploads": u.value, "passes": p.value}
+
+    def stop(self):
+        if self._h:
+            N.host.rth_service_stop(self._h)
+            self._h = None
 
 
 def write_ppm(path, img):

@@ -17,6 +17,9 @@ assert SPHERE_DTYPE.itemsize == 36
 
 MATTE, METAL, DIELECTRIC = 0, 1, 2
 KERNEL_MEGA, KERNEL_WAVEFRONT = 0, 1
+FLAG_PROFILE, FLAG_FULL_SCAN, FLAG_PROGRESSIVE = 1, 2, 4
+ABI_VERSION = 2
+ARITH_SQRT_WIDENED, ARITH_DIV_WIDENED, ARITH_DIV_F32_BY, ARITH_RCP_NARROWED, ARITH_UNIT_FLOAT, ARITH_UNIT_DOUBLE = range(6)
 SCENE_SMALL, SCENE_FINAL, SCENE_DENSE, SCENE_GLASS, SCENE_TRIVIAL = 0, 1, 2, 3, 4
 
 
@@ -43,11 +46,12 @@ class RtJob(C.Structure):
         ("nx", C.c_uint32), ("ny", C.c_uint32), ("row0", C.c_uint32), ("tile_rows", C.c_uint32),
         ("tile_stride", C.c_uint32), ("n_tiles", C.c_uint32), ("nsamples", C.c_uint32), ("max_depth", C.c_uint32),
         ("tmin", C.c_float), ("seed", C.c_uint32), ("kernel", C.c_uint32), ("flags", C.c_uint32),
+        ("sample0", C.c_uint32),
     ]
 
 
 class RtCounters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("paths", "segments", "tests", "candidates", "wave_iterations",
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "segments", "sphere_tests", "box_tests", "candidates", "wave_iterations",
                                           "live_lane_iterations", "cycles_scan", "cycles_drain", "cycles_shade",
                                           "cycles_total", "realtime_total", "own_groups", "wave_groups")]
 
@@ -61,6 +65,11 @@ class RthRenderOpts(C.Structure):
         ("seed", C.c_uint32), ("tile_rows", C.c_uint32), ("kernel", C.c_uint32), ("n_devices", C.c_int),
         ("device_ids", C.POINTER(C.c_int)),
     ]
+
+
+class RthServiceRequest(C.Structure):
+    _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("pass_samples", C.c_uint32), ("target_samples", C.c_uint32),
+                ("max_depth", C.c_uint32), ("seed", C.c_uint32)]
 
 
 class RthRng(C.Structure):
@@ -88,6 +97,10 @@ DEVICE_SYMBOLS = {
     "rt_debug_closest_hit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p,
                                        C.c_void_p]),
     "rt_debug_uniforms": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]),
+    "rt_debug_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "rt_debug_box_pass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_debug_arith": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 HOST_SYMBOLS = {
@@ -106,6 +119,16 @@ HOST_SYMBOLS = {
     "rth_write_png": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "rth_raytrace": (C.c_int, [C.POINTER(RtCamera), C.c_void_p, C.c_size_t, C.POINTER(RthRenderOpts), C.c_void_p,
                                C.POINTER(C.c_float)]),
+    "rth_raytrace_ex": (C.c_int, [C.POINTER(RtCamera), C.c_void_p, C.c_size_t, C.POINTER(RthRenderOpts), C.c_void_p,
+                                  C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "rth_last_error": (C.c_char_p, []),
+    "rth_service_start": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rth_service_submit": (C.c_uint64, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RthServiceRequest)]),
+    "rth_service_latest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rth_service_wait": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
+    "rth_service_stats": (None, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rth_service_stop": (C.c_int, [C.c_void_p]),
 }
 
 
@@ -123,6 +146,8 @@ def _bind(path, table):
 
 device = _bind(DEVICE_LIB, DEVICE_SYMBOLS)
 host = _bind(HOST_LIB, HOST_SYMBOLS)
+if device.rt_abi_version() != ABI_VERSION:
+    raise ImportError(f"{DEVICE_LIB} has ABI version {device.rt_abi_version()}, these bindings are for {ABI_VERSION}: rebuild it")
 
 
 class RtError(RuntimeError):

@@ -74,7 +74,8 @@ constexpr uint32_t kMaxLdsSpheres = RT_MAX_RESIDENT;  // scan positions of a sce
 constexpr uint32_t kBatchSpheres = 512;    // larger scenes: scan positions per staged batch (the LDS footprint of
                                            // a batch is that of the reference's final scene)
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
-constexpr int kNumCounters = 13;
+constexpr int kNumCounters = 14;
+constexpr int kBoxTestCounter = 13;   // (the others are numbered where rt_ctx_counters reads them)
 
 // The scan's arrays are in SCAN order (rt_cluster.h): position -> sphere, pads included.
 struct DeviceScene {
@@ -122,7 +123,8 @@ struct HitState {
   float closest;    // smallest t (the query's tmax while there is no hit)
   int index;        // index of the sphere in the caller's list, -1 for none
   uint32_t cand;    // exact evaluations the wave performed (wave-uniform)
-  uint32_t tests;   // filter tests every ray of the wave had done for it (box tests; without culling: all of them)
+  uint32_t box_tests;    // box tests every ray of the wave had done for it (wave-uniform; culled scan)
+  uint32_t scan_tests;   // sphere filter tests every ray of the wave had done for it (wave-uniform; scan without culling)
   uint32_t lane_tests;   // sphere filter tests this lane evaluated, for whichever ray (culled scan)
   uint32_t own_groups;   // groups this lane's own ray needed (diagnostic: what a per-ray cull would scan)
   uint32_t wave_groups;  // groups the wave scanned
@@ -713,7 +715,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     }
   }
   filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);   // (the pairs name groups of this batch)
-  h.tests += tests;
+  h.box_tests += tests;
 }
 
 // Closest hit of the ray (A, B) of every lane of the workgroup against the
@@ -784,7 +786,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
         cur = nxt;
       }
       if (all_mask != 0ull) mine_lo = mine_hi = ~0ull;
-      h.tests += 2u * n_batch_pairs;
+      h.box_tests += 2u * n_batch_pairs;
       if (w.lane == 0u) {
         lds.bmask[2u * (tid >> 6)] = mine_lo;
         lds.bmask[2u * (tid >> 6) + 1u] = mine_hi;
@@ -818,7 +820,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   } else {
     scan_batch<kCull>(sc, lds, 0u, kCull ? sc.n_pad : sc.n_full, fr, br, alive, uncullable, w, h);
   }
-  if (!kCull) h.tests += sc.n;
+  if (!kCull) h.scan_tests += sc.n;
   const unsigned long long d0 = kProfile ? tick() : 0ull;
   drain_wave(sc, w, h);
   if (kProfile) h.drain_cycles = tick() - d0;
@@ -935,10 +937,13 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   V3 A = v3(0, 0, 0), B = v3(0, 0, 1), color = v3(1, 1, 1);
   Rng g{0u, 0u};
   // event counts of the wave, kept on the scalar unit (ballot popcounts and wave-uniform values)
-  unsigned long long n_seg = 0, n_cand = 0, n_paths = 0, n_tests = 0;
+  // (a launch has fewer than 2^32 paths and a path at most max_depth segments, shared among thousands of waves: the
+  // per-wave counts of paths, segments, candidates and trips fit 32 bits; the test counts may not)
+  uint32_t n_seg = 0, n_cand = 0, n_paths = 0, n_iter = 0;
+  unsigned long long n_tests = 0, n_box = 0;
   uint32_t lane_tests = 0;                    // sphere tests this lane evaluated (culled scan), summed over the wave at the end
   unsigned long long n_own = 0, n_wave = 0;   // per lane, profiling builds only
-  unsigned long long c_scan = 0, c_drain = 0, c_shade = 0, n_iter = 0, n_live = 0;
+  unsigned long long c_scan = 0, c_drain = 0, c_shade = 0;
   const unsigned long long c_begin = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long r_begin = kProfile ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
@@ -960,11 +965,8 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
     if (kProfile) c0 = c1 = c2 = tick();
     if (work) {
       // ---- (1): closest hit
-      if (kProfile) {
-        n_iter++;
-        n_live += (unsigned long long)__popcll(__ballot(alive));
-      }
-      HitState h{0.0f, -1, 0u, 0u, 0u, 0u, 0u, 0ull};   // (closest is read only where index >= 0)
+      n_iter++;
+      HitState h{0.0f, -1, 0u, 0u, 0u, 0u, 0u, 0u, 0ull};   // (closest is read only where index >= 0)
       closest_hit_scene<kBatched, kCull, kProfile>(sc, lds, tid, alive, A, B, job.tmin, kFltMax, h);
       if (kProfile) {
         c2 = tick();
@@ -974,7 +976,8 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
         const uint32_t live = (uint32_t)__popcll(__ballot(alive));
         n_seg += live;
         n_cand += h.cand;
-        n_tests += (unsigned long long)h.tests * live;
+        n_tests += (unsigned long long)h.scan_tests * live;
+        n_box += (unsigned long long)h.box_tests * live;
         lane_tests += h.lane_tests;
       }
       // ---- (2): shade, first part
@@ -1121,7 +1124,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
       }
     }
     RT_STAGE_END(34);
-    n_paths += (unsigned long long)__popcll(__ballot(finished));
+    n_paths += (uint32_t)__popcll(__ballot(finished));
     if (kProfile) {
       unsigned long long c3 = tick();
       c_scan += c1 - c0;
@@ -1142,8 +1145,6 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   }
 
   if (kProfile && lane == 0 && args.counters) {
-    atomicAdd(&args.counters[4], n_iter);
-    atomicAdd(&args.counters[5], n_live);
     atomicAdd(&args.counters[6], c_scan);
     atomicAdd(&args.counters[7], c_drain);
     atomicAdd(&args.counters[8], c_shade);
@@ -1160,23 +1161,28 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   // event counts: one atomic per wave and counter
   n_tests += wave_sum((unsigned long long)lane_tests);
   if (lane == 0 && args.counters) {
-    atomicAdd(&args.counters[0], n_paths);
-    atomicAdd(&args.counters[1], n_seg);
+    atomicAdd(&args.counters[0], (unsigned long long)n_paths);
+    atomicAdd(&args.counters[1], (unsigned long long)n_seg);
     atomicAdd(&args.counters[2], n_tests);
-    atomicAdd(&args.counters[3], n_cand);
+    atomicAdd(&args.counters[3], (unsigned long long)n_cand);
+    atomicAdd(&args.counters[4], (unsigned long long)n_iter);
+    atomicAdd(&args.counters[5], (unsigned long long)n_seg);    // (live lanes summed over the trips = segments)
+    atomicAdd(&args.counters[kBoxTestCounter], n_box);
   }
 }
 
 // Sample accumulation and gamma (c/main.c:462-477): one lane per pixel adds
 // this batch's samples in sample order to the running sum carried in `acc`
 // ({r, g, b sum, hit_sum bits} per pixel) and, on the last batch, divides,
-// takes the square root, scrubs NaN and quantises.
+// takes the square root, scrubs NaN and quantises.  A progressive render keeps
+// the sums after its last batch too, for the call that continues it.
 struct ResolveArgs {
   const float4 *rad;
   float4 *acc;
   int32_t *fh_acc;        // first-hit index of sample 0, carried across batches
-  uint32_t npix, batch, nsamples;
+  uint32_t npix, batch, nsamples;   // nsamples: all samples the sums will hold after this batch's launch sequence
   int first_batch, last_batch;
+  int keep_sum;           // also store the sums on the last batch (RT_FLAG_PROGRESSIVE)
   uint8_t *rgb8;
   float *linear;
   int32_t *first_hit;
@@ -1202,10 +1208,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs args) {
     hsum += (uint32_t)(fh + 1);
     if (args.first_batch && s == 0) fh0 = fh;
   }
-  if (!args.last_batch) {
+  if (!args.last_batch || args.keep_sum) {
     args.acc[p] = make_float4(sum.x, sum.y, sum.z, __int_as_float((int)hsum));
     args.fh_acc[p] = fh0;
-    return;
+    if (!args.last_batch) return;
   }
   V3 mean;
   uint8_t rgb[3];
@@ -1309,7 +1315,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
   __syncthreads();
   int q[kWfSub];
   uint32_t pos[kWfSub];
-  unsigned long long n_seg = 0, n_cand = 0, n_tests = 0;   // of the wave (wave-uniform)
+  unsigned long long n_seg = 0, n_cand = 0, n_tests = 0, n_box = 0;   // of the wave (wave-uniform)
   uint32_t lane_tests = 0;
 #pragma unroll 1
   for (int sub = 0; sub < kWfSub; ++sub) {
@@ -1328,13 +1334,14 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
       A = v3(o.x, o.y, o.z);
       B = v3(d.x, d.y, d.z);
     }
-    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u, 0ull};
+    HitState h{kFltMax, -1, 0u, 0u, 0u, 0u, 0u, 0u, 0ull};
     closest_hit_scene<kBatched, kCull>(sc, lds, tid, alive, A, B, args.geo.job.tmin, kFltMax, h);
     {
       const uint32_t live = (uint32_t)__popcll(__ballot(alive));
       n_seg += live;
       n_cand += h.cand;
-      n_tests += (unsigned long long)h.tests * live;
+      n_tests += (unsigned long long)h.scan_tests * live;
+      n_box += (unsigned long long)h.box_tests * live;
       lane_tests += h.lane_tests;
     }
     if (alive) {
@@ -1360,6 +1367,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
     atomicAdd(&args.counters[1], n_seg);
     atomicAdd(&args.counters[2], n_tests);
     atomicAdd(&args.counters[3], n_cand);
+    atomicAdd(&args.counters[kBoxTestCounter], n_box);
   }
 }
 
@@ -1441,7 +1449,7 @@ __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene 
     A = v3(rays[6 * r + 0], rays[6 * r + 1], rays[6 * r + 2]);
     B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
   }
-  HitState h{tmax, -1, 0u, 0u, 0u, 0u, 0u, 0ull};
+  HitState h{tmax, -1, 0u, 0u, 0u, 0u, 0u, 0u, 0ull};
   closest_hit_scene<true, kCull>(sc, lds, tid, alive, A, B, tmin, tmax, h);
   if (alive) {
     index[r] = h.index;
@@ -1454,6 +1462,104 @@ __global__ void uniforms_kernel(uint32_t seed, uint32_t pixel, uint32_t sample, 
   if (i >= n) return;
   Rng g{path_key(seed, pixel, sample), i};
   out[i] = next_uniform(g);
+}
+
+
+// The filter routines on caller-supplied operands: every lane takes one ray and runs the pair image
+// `pairs` (n_spheres entries, groups of eight) through filter_four_pairs, with the coefficients packed as
+// the full scan packs them, and through filter_two_pairs, with the coefficients rebuilt from the ray
+// table entries as the culled scan rebuilds them.
+__global__ __launch_bounds__(kBlockThreads) void debug_filter_kernel(const float *rays, uint32_t n_rays, const float4 *pairs,
+                                                                     uint32_t n_spheres, float *df_four, float *df_two) {
+  const uint32_t r = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (r >= n_rays) return;
+  const V3 A = v3(rays[6 * r + 0], rays[6 * r + 1], rays[6 * r + 2]), B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
+  const FilterRay f = make_filter_ray(A, B);
+  const FilterRayP fr = pack_ray(f);
+  // what closest_hit_scene keeps in the ray table, and what filter_listed_pairs makes of it
+  const float4 ra = make_float4(A.x, A.y, A.z, dot(B, B)), rb = make_float4(B.x, B.y, B.z, f.na), rc = make_float4(0.0f, 0.0f, f.ab, f.naaa);
+  FilterRayP f2;
+  f2.p0 = f32x2{-rb.x, -rb.y};
+  f2.p1 = f32x2{-rb.z, rc.z};
+  f2.p2 = f32x2{-2.0f * ra.x, -2.0f * ra.y};
+  f2.p3 = f32x2{-2.0f * ra.z, rb.w};
+  f2.p4 = f32x2{rc.w, 0.0f};
+  for (uint32_t g = 0; g < n_spheres; g += kChunk) {
+    float4 q[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) q[u] = pairs[g + u];
+    f32x2 d[kChunk / 2];
+    filter_four_pairs(fr, q, d);
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) df_four[(size_t)r * n_spheres + g + u] = d[u >> 1][u & 1];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float4 qq[4] = {q[4 * half], q[4 * half + 1], q[4 * half + 2], q[4 * half + 3]};
+      f32x2 d0, d1;
+      filter_two_pairs(f2, qq, d0, d1);
+      float *dst = df_two + (size_t)r * n_spheres + g + 4 * half;
+      dst[0] = d0[0];
+      dst[1] = d0[1];
+      dst[2] = d1[0];
+      dst[3] = d1[1];
+    }
+  }
+}
+
+// The box routines on caller-supplied operands: `boxes` holds pairs of boxes in the layout of
+// DeviceScene::boxes (3 entries per pair).  box_pair reads them from vector registers, box_pair_scalar
+// through scalar loads.
+__global__ __launch_bounds__(kBlockThreads) void debug_box_kernel(const float *rays, uint32_t n_rays, const float4 *boxes, uint32_t n_boxes,
+                                                                  float sigma0, float sigma1, uint8_t *pass_vec, uint8_t *pass_sca, float *box_ray) {
+  const uint32_t r = blockIdx.x * kBlockThreads + threadIdx.x;
+  const bool mine = r < n_rays;
+  V3 A = v3(0, 0, 0), B = v3(1, 1, 1);
+  if (mine) {
+    A = v3(rays[6 * r + 0], rays[6 * r + 1], rays[6 * r + 2]);
+    B = v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
+  }
+  const BoxRay b = make_box_ray(A, B, sigma0, sigma1);
+  const BoxRayP br = pack_box_ray(b);
+  if (mine) {
+    const float v[9] = {b.ix, b.iy, b.iz, b.nx, b.ny, b.nz, b.ax, b.ay, b.az};
+    for (int k = 0; k < 9; ++k) box_ray[9 * (size_t)r + k] = v[k];
+  }
+  typedef __attribute__((address_space(4))) const float *ScalarFloats;
+  const ScalarFloats sb = (ScalarFloats)(uintptr_t)boxes;
+  for (uint32_t q = 0; q < n_boxes / 2u; ++q) {   // (every lane of the wave takes every trip: the scalar loads are wave-uniform)
+    const float4 vq[3] = {boxes[3 * q], boxes[3 * q + 1], boxes[3 * q + 2]};
+    bool pv[2], ps[2];
+    box_pair(br, vq, pv);
+    const ScalarFloats e = sb + 12u * q;
+    const BoxPairS sq{f32x2{e[0], e[1]}, f32x2{e[2], e[3]}, f32x2{e[4], e[5]}, f32x2{e[6], e[7]}, f32x2{e[8], e[9]}, f32x2{e[10], e[11]}};
+    box_pair_scalar(br, sq, ps);
+    if (mine) {
+      pass_vec[(size_t)r * n_boxes + 2 * q] = pv[0];
+      pass_vec[(size_t)r * n_boxes + 2 * q + 1] = pv[1];
+      pass_sca[(size_t)r * n_boxes + 2 * q] = ps[0];
+      pass_sca[(size_t)r * n_boxes + 2 * q + 1] = ps[1];
+    }
+  }
+}
+
+__global__ void debug_arith_kernel(int op, const double *a, const double *b, uint32_t n, double *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0;
+  double r = 0.0;
+  switch (op) {
+    case RT_ARITH_SQRT_WIDENED: r = sqrt_of_widened_positive_float((double)(float)x); break;
+    case RT_ARITH_DIV_WIDENED: {
+      const double da = (double)(float)y;
+      r = div_by_widened_float(x, da, 1.0 / da);
+    } break;
+    case RT_ARITH_DIV_F32_BY: r = (double)div_f32_by((float)x, (float)y, 1.0 / (double)(float)y); break;
+    case RT_ARITH_RCP_NARROWED: r = (double)narrowed_double_reciprocal((float)x); break;
+    case RT_ARITH_UNIT_FLOAT: r = (double)unit_float_from_bits((uint32_t)x); break;
+    case RT_ARITH_UNIT_DOUBLE: r = unit_from_bits((uint32_t)x); break;
+    default: break;
+  }
+  out[i] = r;
 }
 
 // ------------------------------------------------------------------ host side
@@ -1495,8 +1601,19 @@ struct DevBuf {
 
 }  // namespace
 
+// what a progressive render leaves behind for the call that continues it
+struct ProgressiveState {
+  bool valid = false;
+  rt_camera cam;
+  rt_job job;               // the geometry fields, seed, depth, tmin of the call that made the sums
+  uint32_t samples = 0;     // samples the sums hold
+  unsigned long scene_generation = 0;
+};
+
 struct rt_ctx {
   int device = 0;
+  ProgressiveState progressive;
+  unsigned long scene_generation = 0;        // bumped by every rt_scene_upload
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the whole of the last render
@@ -1544,6 +1661,7 @@ int check_job(const rt_job *job) {
   if ((uint64_t)job->nx * job->ny > 0xffffffffull) return fail(RT_ERR_LIMIT, "more than 2^32 pixels");
   if (job->kernel != RT_KERNEL_MEGA && job->kernel != RT_KERNEL_WAVEFRONT)
     return fail(RT_ERR_ARG, "unknown kernel variant");
+  if ((uint64_t)job->sample0 + job->nsamples > 0xffffffffull) return fail(RT_ERR_LIMIT, "sample indices beyond 2^32");
   return RT_OK;
 }
 
@@ -1611,19 +1729,53 @@ int run_wavefront_batch(rt_ctx *c, const TraceArgs &t, uint32_t valid_paths, boo
   return RT_OK;
 }
 
-int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *rgb8, float *linear, int32_t *first_hit,
-                  uint32_t *hit_sum) {
+// Device memory one render works in, beyond its inputs and outputs.
+struct Workspace {
+  float4 *rad;               // per-path radiance of one sample batch: batch * npix entries
+  float4 *acc;               // running per-pixel sums between batches (needed when batch < nsamples or progressive)
+  int32_t *fh_acc;
+  unsigned int *queue;       // work-queue head of the trace kernel
+  unsigned long long *counters;
+  uint32_t batch;            // samples per launch
+};
+
+// the persistent grid of a trace-kernel variant: as many workgroups as the device holds at the
+// variant's occupancy (registers and LDS decide: five per CU for the culled scan of a scene the size
+// of the reference's, fewer otherwise); asked once per kernel and LDS size
+const void *trace_kernel_fn(bool batched, bool cull_scan, bool profile) {
+#define RT_TRACE_FN(B, C, P) reinterpret_cast<const void *>(&trace_kernel<B, C, P>)
+  if (!batched && cull_scan && !profile) return RT_TRACE_FN(false, true, false);
+  if (!batched && cull_scan && profile) return RT_TRACE_FN(false, true, true);
+  if (!batched && !cull_scan && !profile) return RT_TRACE_FN(false, false, false);
+  if (!batched && !cull_scan && profile) return RT_TRACE_FN(false, false, true);
+  if (batched && cull_scan && !profile) return RT_TRACE_FN(true, true, false);
+  if (batched && cull_scan && profile) return RT_TRACE_FN(true, true, true);
+  if (batched && !cull_scan && !profile) return RT_TRACE_FN(true, false, false);
+  return RT_TRACE_FN(true, false, true);
+#undef RT_TRACE_FN
+}
+
+int trace_blocks_per_cu(rt_ctx *c, const void *kernel_fn, size_t lds, int *out) {
+  int &per_cu = c->blocks_per_cu[std::make_pair(kernel_fn, lds)];
+  if (per_cu == 0) RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_fn, kBlockThreads, lds));
+  if (per_cu < 1) return fail(RT_ERR_HIP, "the trace kernel does not fit a compute unit");
+  *out = per_cu;
+  return RT_OK;
+}
+
+// `record`: time the trace kernels with the context's event pairs (created on demand; a caller that
+// must not create anything passes false)
+int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Workspace &ws, bool record, uint8_t *rgb8,
+                  float *linear, int32_t *first_hit, uint32_t *hit_sum) {
   static_assert(sizeof(Camera) == sizeof(rt_camera), "camera layouts differ");
   const uint32_t rows = rt_job_rows(job);
   const uint32_t npix = rows * job->nx;
   const uint32_t tiles_x = (job->nx + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
-  const uint32_t batch = batch_size(npix, job->nsamples);
+  const uint32_t batch = ws.batch;
   if ((uint64_t)tiles_x * tiles_y * batch * 64u > 0xfffffff0ull - 4ull * kWfSlots)
     return fail(RT_ERR_LIMIT, "too many paths in one launch");
-  int rc;
-  if ((rc = c->rad.reserve((size_t)batch * npix))) return rc;
-  const bool multi = batch < job->nsamples;
-  if (multi && ((rc = c->acc.reserve(npix)) || (rc = c->fh_acc.reserve(npix)))) return rc;
+  const bool progressive = (job->flags & RT_FLAG_PROGRESSIVE) != 0;
+  const uint32_t nsamples_total = job->sample0 + job->nsamples;
 
   TraceArgs t;
   std::memcpy(&t.cam, cam, sizeof t.cam);
@@ -1631,46 +1783,33 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
   t.geo.rows = rows;
   t.geo.tiles_x = tiles_x;
   t.sc = scene_view(c);
-  t.rad = c->rad.p;
-  t.queue = c->queue.p;
-  t.counters = c->counters.p;
-  size_t lds = trace_lds_bytes(c->n_pad, (job->flags & RT_FLAG_FULL_SCAN) == 0);
+  t.rad = ws.rad;
+  t.queue = ws.queue;
+  t.counters = ws.counters;
+  const bool cull_scan = (job->flags & RT_FLAG_FULL_SCAN) == 0;
+  size_t lds = trace_lds_bytes(c->n_pad, cull_scan);
 #if RT_EXP == 41   // occupancy experiment: pad the LDS request so that only three workgroups fit a CU
   lds += 10240;
 #endif
   const bool batched = c->n_pad > kMaxLdsSpheres, profile = (job->flags & RT_FLAG_PROFILE) != 0;
-  // persistent workgroups: as many as the device holds at the chosen kernel's occupancy (registers and
-  // LDS decide: five per CU for the culled scan of a scene the size of the reference's, fewer otherwise)
-  const bool cull_scan = (job->flags & RT_FLAG_FULL_SCAN) == 0;
-  const void *kernel_fn = nullptr;
-#define RT_TRACE_FN(B, C, P) reinterpret_cast<const void *>(&trace_kernel<B, C, P>)
-  if (!batched && cull_scan && !profile) kernel_fn = RT_TRACE_FN(false, true, false);
-  if (!batched && cull_scan && profile) kernel_fn = RT_TRACE_FN(false, true, true);
-  if (!batched && !cull_scan && !profile) kernel_fn = RT_TRACE_FN(false, false, false);
-  if (!batched && !cull_scan && profile) kernel_fn = RT_TRACE_FN(false, false, true);
-  if (batched && cull_scan && !profile) kernel_fn = RT_TRACE_FN(true, true, false);
-  if (batched && cull_scan && profile) kernel_fn = RT_TRACE_FN(true, true, true);
-  if (batched && !cull_scan && !profile) kernel_fn = RT_TRACE_FN(true, false, false);
-  if (batched && !cull_scan && profile) kernel_fn = RT_TRACE_FN(true, false, true);
-#undef RT_TRACE_FN
-  int &per_cu = c->blocks_per_cu[std::make_pair(kernel_fn, lds)];   // (asked once per kernel and LDS size)
-  if (per_cu == 0) RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_fn, kBlockThreads, lds));
-  if (per_cu < 1) return fail(RT_ERR_HIP, "the trace kernel does not fit a compute unit");
+  const void *kernel_fn = trace_kernel_fn(batched, cull_scan, profile);
+  int per_cu = 0, rc;
+  if ((rc = trace_blocks_per_cu(c, kernel_fn, lds, &per_cu))) return rc;
   const dim3 grid((unsigned)(c->num_cus * per_cu)), block(kBlockThreads);
 
   const int slot = (int)(c->renders % rt_ctx::kHistory);
   auto &pairs = c->trace_events[slot];
   int used = 0;
-  RT_HIP(hipEventRecord(c->ev_begin, c->stream));
+  if (record) RT_HIP(hipEventRecord(c->ev_begin, c->stream));
   for (uint32_t s0 = 0; s0 < job->nsamples; s0 += batch) {
-    if ((int)pairs.size() <= used) {
+    if (record && (int)pairs.size() <= used) {
       hipEvent_t e0, e1;
       RT_HIP(hipEventCreate(&e0));
       RT_HIP(hipEventCreate(&e1));
       pairs.emplace_back(e0, e1);
     }
     const uint32_t sb = job->nsamples - s0 < batch ? job->nsamples - s0 : batch;
-    t.geo.sample0 = s0;
+    t.geo.sample0 = job->sample0 + s0;
     t.geo.batch = sb;
     t.geo.inv_nx = 1.0 / (double)(float)job->nx;
     t.geo.inv_ny = 1.0 / (double)(float)job->ny;
@@ -1678,25 +1817,28 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
                             ? (uint32_t)(((1ull << 32) + job->tile_rows - 1) / job->tile_rows)
                             : 0u;
     t.geo.total_items = tiles_x * tiles_y * sb * 64u;
-    RT_HIP(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), c->stream));
-    RT_HIP(hipEventRecord(pairs[used].first, c->stream));
+    RT_HIP(hipMemsetAsync(ws.queue, 0, sizeof(unsigned int), c->stream));
+    if (record) RT_HIP(hipEventRecord(pairs[used].first, c->stream));
     if (job->kernel == RT_KERNEL_WAVEFRONT) {
       if ((rc = run_wavefront_batch(c, t, npix * sb, batched, lds))) return rc;
     } else {
       void *kernel_args[] = {&t};
       RT_HIP(hipLaunchKernel(kernel_fn, grid, block, kernel_args, lds, c->stream));
     }
-    RT_HIP(hipEventRecord(pairs[used].second, c->stream));
-    ++used;
+    if (record) {
+      RT_HIP(hipEventRecord(pairs[used].second, c->stream));
+      ++used;
+    }
     ResolveArgs r;
-    r.rad = c->rad.p;
-    r.acc = c->acc.p;
-    r.fh_acc = c->fh_acc.p;
+    r.rad = ws.rad;
+    r.acc = ws.acc;
+    r.fh_acc = ws.fh_acc;
     r.npix = npix;
     r.batch = sb;
-    r.nsamples = job->nsamples;
-    r.first_batch = s0 == 0;
+    r.nsamples = nsamples_total;
+    r.first_batch = job->sample0 == 0 && s0 == 0;
     r.last_batch = s0 + sb >= job->nsamples;
+    r.keep_sum = progressive;
     r.rgb8 = rgb8;
     r.linear = linear;
     r.first_hit = first_hit;
@@ -1704,13 +1846,43 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *r
     hipLaunchKernelGGL(resolve_kernel, dim3((npix + 255u) / 256u), dim3(256), 0, c->stream, r);
     RT_HIP(hipGetLastError());
   }
-  RT_HIP(hipEventRecord(c->ev_end, c->stream));
-  c->trace_used[slot] = used;
-  c->renders++;
-  c->timed = true;
+  if (record) {
+    RT_HIP(hipEventRecord(c->ev_end, c->stream));
+    c->trace_used[slot] = used;
+    c->renders++;
+    c->timed = true;
+  }
   return RT_OK;
 }
 
+// the fields of a job that must not change between the calls of one progressive render
+bool same_progressive_render(const ProgressiveState &p, const rt_camera *cam, const rt_job *job, unsigned long scene_generation) {
+  const rt_job &q = p.job;
+  return p.valid && p.scene_generation == scene_generation && std::memcmp(&p.cam, cam, sizeof *cam) == 0 && q.nx == job->nx &&
+         q.ny == job->ny && q.row0 == job->row0 && q.tile_rows == job->tile_rows && q.tile_stride == job->tile_stride &&
+         q.n_tiles == job->n_tiles && q.max_depth == job->max_depth && std::memcmp(&q.tmin, &job->tmin, sizeof q.tmin) == 0 &&
+         q.seed == job->seed;
+}
+
+}  // namespace
+
+namespace {
+// host arrays to the device, a kernel, device arrays back: the plumbing of the unit-level entry points
+struct DebugBuffers {
+  std::vector<std::pair<void *, size_t>> bufs;
+  ~DebugBuffers() {
+    for (auto &b : bufs) (void)hipFree(b.first);
+  }
+  template <typename T>
+  int get(size_t n, T **out, const void *init = nullptr) {
+    void *p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T) + 16) != hipSuccess) return fail(RT_ERR_NOMEM, "hipMalloc failed");
+    bufs.emplace_back(p, n * sizeof(T));
+    if (init && hipMemcpy(p, init, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return fail(RT_ERR_HIP, "hipMemcpy to device failed");
+    *out = static_cast<T *>(p);
+    return RT_OK;
+  }
+};
 }  // namespace
 
 extern "C" {
@@ -1915,6 +2087,8 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->inv_r_o.p, inv_r_o.data(), n * sizeof(double), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->group_real.p, L.real_in_group.data(), n_pad / 8, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
+  c->scene_generation++;
+  c->progressive.valid = false;
   c->n = (uint32_t)n;
   c->n_pad = n_pad;
   c->n_always_groups = L.n_always_groups;
@@ -1924,6 +2098,12 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   for (uint32_t p = 0; p < n_pad; ++p)
     if (L.order[p] != 0xffffffffu) last_real = p;
   c->n_full = (last_real / 16u + 1u) * 16u;
+  // the occupancy of the trace-kernel variants this scene can run, asked now so that a render never has to
+  for (int variant = 0; variant < 4; ++variant) {
+    const bool cull = (variant & 1) != 0, profile = (variant & 2) != 0, batched = n_pad > kMaxLdsSpheres;
+    int per_cu = 0;
+    if ((rc = trace_blocks_per_cu(c, trace_kernel_fn(batched, cull, profile), trace_lds_bytes(n_pad, cull), &per_cu))) return rc;
+  }
   return RT_OK;
 }
 
@@ -1933,9 +2113,38 @@ int rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t
   int rc = check_job(job);
   if (rc != RT_OK) return rc;
   if (c->n == 0) return fail(RT_ERR_NO_SCENE, "no scene uploaded");
-  if (rt_job_rows(job) == 0) return fail(RT_ERR_ARG, "job covers no rows");
+  const uint32_t rows = rt_job_rows(job);
+  if (rows == 0) return fail(RT_ERR_ARG, "job covers no rows");
+  const bool progressive = (job->flags & RT_FLAG_PROGRESSIVE) != 0;
+  if (job->sample0 != 0) {
+    if (!progressive) return fail(RT_ERR_ARG, "sample0 > 0 needs RT_FLAG_PROGRESSIVE");
+    if (!same_progressive_render(c->progressive, cam, job, c->scene_generation) || c->progressive.samples != job->sample0)
+      return fail(RT_ERR_ARG, "no running sums of this render that end at sample0 (scene, camera, geometry, seed, depth and "
+                              "tmin must be those of the progressive call before)");
+  }
   RT_HIP(hipSetDevice(c->device));
-  return launch_render(c, cam, job, d_rgb8, d_linear, d_first_hit, d_hit_sum);
+  const uint32_t npix = rows * job->nx;
+  Workspace ws;
+  ws.batch = batch_size(npix, job->nsamples);
+  if ((rc = c->rad.reserve((size_t)ws.batch * npix))) return rc;
+  // (reserve keeps what a buffer holds unless it has to grow, and the sums of a progressive render were
+  // reserved for the same npix)
+  if ((ws.batch < job->nsamples || progressive) && ((rc = c->acc.reserve(npix)) || (rc = c->fh_acc.reserve(npix)))) return rc;
+  ws.rad = c->rad.p;
+  ws.acc = c->acc.p;
+  ws.fh_acc = c->fh_acc.p;
+  ws.queue = c->queue.p;
+  ws.counters = c->counters.p;
+  c->progressive.valid = false;   // (whatever happens below, the sums are no longer those of the render before)
+  rc = launch_render(c, cam, job, ws, true, d_rgb8, d_linear, d_first_hit, d_hit_sum);
+  if (rc == RT_OK && progressive) {
+    c->progressive.valid = true;
+    c->progressive.cam = *cam;
+    c->progressive.job = *job;
+    c->progressive.samples = job->sample0 + job->nsamples;
+    c->progressive.scene_generation = c->scene_generation;
+  }
+  return rc;
 }
 
 int rt_render_host(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *h_rgb8, float *h_linear,
@@ -1999,7 +2208,8 @@ int rt_ctx_counters(rt_ctx *c, rt_counters *out, int reset) {
     RT_HIP(hipMemcpy(v, c->counters.p, sizeof v, hipMemcpyDeviceToHost));
     out->paths = v[0];
     out->segments = v[1];
-    out->tests = v[2];
+    out->sphere_tests = v[2];
+    out->box_tests = v[kBoxTestCounter];
     out->candidates = v[3];
     out->wave_iterations = v[4];
     out->live_lane_iterations = v[5];
@@ -2061,6 +2271,87 @@ int rt_debug_uniforms(rt_ctx *c, uint32_t seed, uint32_t pixel, uint32_t sample,
   if (e == hipSuccess) e = hipMemcpy(out, d.p, n * sizeof(double), hipMemcpyDeviceToHost);
   d.release();
   if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("uniforms: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+
+
+int rt_debug_filter(rt_ctx *c, const float *rays, size_t n_rays, const float *spheres, size_t n_spheres, float *df_four, float *df_two) {
+  if (!c || !rays || !spheres || !df_four || !df_two) return fail(RT_ERR_ARG, "null argument");
+  if (n_rays == 0 || n_spheres == 0) return RT_OK;
+  if (n_spheres % kChunk) return fail(RT_ERR_ARG, "n_spheres must be a multiple of 8");
+  if (n_rays * n_spheres > (1ull << 28)) return fail(RT_ERR_LIMIT, "too many pairs");
+  RT_HIP(hipSetDevice(c->device));
+  std::vector<float4> pairs(n_spheres);
+  for (size_t p2 = 0; p2 < n_spheres; p2 += 2) {
+    const FilterSphere s0 = make_filter_sphere(spheres[4 * p2], spheres[4 * p2 + 1], spheres[4 * p2 + 2], spheres[4 * p2 + 3]);
+    const FilterSphere s1 = make_filter_sphere(spheres[4 * p2 + 4], spheres[4 * p2 + 5], spheres[4 * p2 + 6], spheres[4 * p2 + 7]);
+    pairs[p2] = make_float4(s0.cx, s1.cx, s0.cy, s1.cy);
+    pairs[p2 + 1] = make_float4(s0.cz, s1.cz, s0.kprime, s1.kprime);
+  }
+  DebugBuffers d;
+  float *d_rays, *d_four, *d_two;
+  float4 *d_pairs;
+  int rc;
+  if ((rc = d.get(6 * n_rays, &d_rays, rays)) || (rc = d.get(n_spheres, &d_pairs, pairs.data())) ||
+      (rc = d.get(n_rays * n_spheres, &d_four)) || (rc = d.get(n_rays * n_spheres, &d_two)))
+    return rc;
+  hipLaunchKernelGGL(debug_filter_kernel, dim3((unsigned)((n_rays + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, c->stream,
+                     d_rays, (uint32_t)n_rays, d_pairs, (uint32_t)n_spheres, d_four, d_two);
+  RT_HIP(hipGetLastError());
+  RT_HIP(hipStreamSynchronize(c->stream));
+  RT_HIP(hipMemcpy(df_four, d_four, n_rays * n_spheres * sizeof(float), hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(df_two, d_two, n_rays * n_spheres * sizeof(float), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_debug_box_pass(rt_ctx *c, const float *rays, size_t n_rays, const float *boxes, size_t n_boxes, float sigma0, float sigma1,
+                      uint8_t *pass_vec, uint8_t *pass_sca, float *box_ray) {
+  if (!c || !rays || !boxes || !pass_vec || !pass_sca || !box_ray) return fail(RT_ERR_ARG, "null argument");
+  if (n_rays == 0 || n_boxes == 0) return RT_OK;
+  if (n_boxes % 2) return fail(RT_ERR_ARG, "n_boxes must be even");
+  if (n_rays * n_boxes > (1ull << 28)) return fail(RT_ERR_LIMIT, "too many pairs");
+  RT_HIP(hipSetDevice(c->device));
+  std::vector<float4> packed(3 * (n_boxes / 2));
+  for (size_t q = 0; q < n_boxes / 2; ++q) {
+    const float *b0 = boxes + 12 * q, *b1 = b0 + 6;
+    packed[3 * q] = make_float4(b0[0], b1[0], b0[1], b1[1]);
+    packed[3 * q + 1] = make_float4(b0[2], b1[2], b0[3], b1[3]);
+    packed[3 * q + 2] = make_float4(b0[4], b1[4], b0[5], b1[5]);
+  }
+  DebugBuffers d;
+  float *d_rays, *d_box_ray;
+  float4 *d_boxes;
+  uint8_t *d_vec, *d_sca;
+  int rc;
+  if ((rc = d.get(6 * n_rays, &d_rays, rays)) || (rc = d.get(packed.size(), &d_boxes, packed.data())) ||
+      (rc = d.get(n_rays * n_boxes, &d_vec)) || (rc = d.get(n_rays * n_boxes, &d_sca)) || (rc = d.get(9 * n_rays, &d_box_ray)))
+    return rc;
+  hipLaunchKernelGGL(debug_box_kernel, dim3((unsigned)((n_rays + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, c->stream,
+                     d_rays, (uint32_t)n_rays, d_boxes, (uint32_t)n_boxes, sigma0, sigma1, d_vec, d_sca, d_box_ray);
+  RT_HIP(hipGetLastError());
+  RT_HIP(hipStreamSynchronize(c->stream));
+  RT_HIP(hipMemcpy(pass_vec, d_vec, n_rays * n_boxes, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(pass_sca, d_sca, n_rays * n_boxes, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(box_ray, d_box_ray, 9 * n_rays * sizeof(float), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_debug_arith(rt_ctx *c, int op, const double *a, const double *b, size_t n, double *out) {
+  if (!c || !a || !out) return fail(RT_ERR_ARG, "null argument");
+  if (op < RT_ARITH_SQRT_WIDENED || op > RT_ARITH_UNIT_DOUBLE) return fail(RT_ERR_ARG, "unknown operation");
+  if ((op == RT_ARITH_DIV_WIDENED || op == RT_ARITH_DIV_F32_BY) && !b) return fail(RT_ERR_ARG, "the operation needs a divisor array");
+  if (n == 0) return RT_OK;
+  if (n > (1u << 26)) return fail(RT_ERR_LIMIT, "too many operands");
+  RT_HIP(hipSetDevice(c->device));
+  DebugBuffers d;
+  double *d_a, *d_b = nullptr, *d_out;
+  int rc;
+  if ((rc = d.get(n, &d_a, a)) || (b && (rc = d.get(n, &d_b, b))) || (rc = d.get(n, &d_out))) return rc;
+  hipLaunchKernelGGL(debug_arith_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, op, d_a, d_b, (uint32_t)n, d_out);
+  RT_HIP(hipGetLastError());
+  RT_HIP(hipStreamSynchronize(c->stream));
+  RT_HIP(hipMemcpy(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost));
   return RT_OK;
 }
 

@@ -15,6 +15,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* text of the first failure of the last rth_raytrace / service call on this thread (rt_last_error() is
+ * per thread, and the failing call ran on a device thread) */
+static _Thread_local char g_err[256];
+const char *rth_last_error(void) { return g_err; }
+void rth_set_error(const char *text) {
+  strncpy(g_err, text ? text : "", sizeof g_err - 1);
+  g_err[sizeof g_err - 1] = 0;
+}
+
 typedef struct {
   const rt_camera *cam;
   const rt_sphere *spheres;
@@ -82,14 +91,16 @@ static void *device_thread(void *arg) {
   return NULL;
 }
 
-int rth_raytrace(const rt_camera *cam, const rt_sphere *spheres, size_t n, const rth_render_opts *opts, uint8_t *rgb8,
-                 float *kernel_ms_max) {
-  if (!cam || !spheres || !opts || !rgb8 || n == 0) return RT_ERR_ARG;
-  if (opts->n_devices <= 0 || opts->tile_rows == 0 || opts->nx == 0 || opts->ny == 0) return RT_ERR_ARG;
+int rth_raytrace_ex(const rt_camera *cam, const rt_sphere *spheres, size_t n, const rth_render_opts *opts, uint8_t *rgb8,
+                    float *kernel_ms_max, int *devices_used) {
+  g_err[0] = 0;
+  if (devices_used) *devices_used = 0;
+  if (!cam || !spheres || !opts || !rgb8 || n == 0) { rth_set_error("null or empty argument"); return RT_ERR_ARG; }
+  if (opts->n_devices <= 0 || opts->tile_rows == 0 || opts->nx == 0 || opts->ny == 0) { rth_set_error("zero size or device count"); return RT_ERR_ARG; }
   int present = 0;
   int rc = rt_device_count(&present);
-  if (rc != RT_OK) return rc;
-  if (present <= 0) return RT_ERR_HIP;
+  if (rc != RT_OK) { rth_set_error(rt_last_error()); return rc; }
+  if (present <= 0) { rth_set_error("no GPU present"); return RT_ERR_HIP; }
   int world = opts->n_devices;
   dev_job *jobs = (dev_job *)calloc((size_t)world, sizeof *jobs);
   pthread_t *tid = (pthread_t *)calloc((size_t)world, sizeof *tid);
@@ -105,13 +116,31 @@ int rth_raytrace(const rt_camera *cam, const rt_sphere *spheres, size_t n, const
     if (pthread_create(&tid[r], NULL, device_thread, &jobs[r]) != 0) { rc = RT_ERR_NOMEM; break; }
     started++;
   }
+  if (rc != RT_OK) rth_set_error("could not start a device thread");
   float worst = 0.0f;
   for (int r = 0; r < started; r++) {
     pthread_join(tid[r], NULL);
-    if (jobs[r].rc != RT_OK && rc == RT_OK) rc = jobs[r].rc;
+    if (jobs[r].rc != RT_OK && rc == RT_OK) {
+      rc = jobs[r].rc;
+      rth_set_error(jobs[r].err);       /* the cause, from the thread that saw it */
+    }
     if (jobs[r].kernel_ms > worst) worst = jobs[r].kernel_ms;
   }
   if (kernel_ms_max) *kernel_ms_max = worst;
+  if (devices_used) {                   /* distinct devices: ranks beyond the devices present wrap onto them */
+    int distinct = 0;
+    for (int r = 0; r < world; r++) {
+      int seen = 0;
+      for (int q = 0; q < r; q++) seen |= jobs[q].device == jobs[r].device;
+      distinct += !seen;
+    }
+    *devices_used = distinct;
+  }
   free(jobs); free(tid);
   return rc;
+}
+
+int rth_raytrace(const rt_camera *cam, const rt_sphere *spheres, size_t n, const rth_render_opts *opts, uint8_t *rgb8,
+                 float *kernel_ms_max) {
+  return rth_raytrace_ex(cam, spheres, n, opts, rgb8, kernel_ms_max, NULL);
 }

@@ -65,6 +65,39 @@ typedef struct {
 
 int rth_raytrace(const rt_camera *cam, const rt_sphere *spheres, size_t n, const rth_render_opts *opts, uint8_t *rgb8,
                  float *kernel_ms_max);
+/* the same; devices_used, if not NULL, receives the number of distinct GPUs the ranks ran on */
+int rth_raytrace_ex(const rt_camera *cam, const rt_sphere *spheres, size_t n, const rth_render_opts *opts, uint8_t *rgb8,
+                    float *kernel_ms_max, int *devices_used);
+/* text of the first failure of the last rth_* call on this thread (the failing library call may have run on
+ * another thread, whose rt_last_error() the caller cannot see) */
+const char *rth_last_error(void);
+void rth_set_error(const char *text);
+
+/* ---- render service: one GPU context and scene kept resident by a worker thread that re-renders when
+ * a new camera arrives and refines the picture while the camera rests -- what the reference's
+ * interactive front end does with its worker thread and job channel (rs/src/gui.rs:164-172, 340-357),
+ * with progressive passes instead of one fixed-size render per request.
+ *
+ * rth_service_start uploads the scene once.  rth_service_submit replaces the pending request (the newest
+ * camera wins); the worker renders it in passes of pass_samples samples, each pass continuing the sums
+ * of the one before (RT_FLAG_PROGRESSIVE), until target_samples are in the picture or a newer request
+ * arrives.  After every pass the picture so far is published; rth_service_latest copies it out with its
+ * request id and sample count.  rth_service_wait blocks until request `id` has reached min_samples (or
+ * failed).  rth_service_stop joins the worker and frees everything. */
+typedef struct rth_service rth_service;
+typedef struct {
+  uint32_t nx, ny, pass_samples, target_samples, max_depth, seed;
+} rth_service_request;
+int rth_service_start(int device, const rt_sphere *spheres, size_t n, rth_service **out);
+/* returns the id of the request (1, 2, ...) or 0 on a bad argument */
+uint64_t rth_service_submit(rth_service *s, const rt_camera *cam, const rth_service_request *req);
+/* rgb8: 3*nx*ny bytes of the request the picture belongs to (cap = its size in bytes); returns RT_OK,
+ * RT_ERR_ARG when cap is too small or nothing has been published yet */
+int rth_service_latest(rth_service *s, uint8_t *rgb8, size_t cap, uint64_t *id, uint32_t *samples, uint32_t *nx, uint32_t *ny);
+int rth_service_wait(rth_service *s, uint64_t id, uint32_t min_samples);
+/* scene uploads and render passes the worker has made so far */
+void rth_service_stats(rth_service *s, uint64_t *uploads, uint64_t *passes);
+int rth_service_stop(rth_service *s);
 
 #ifdef __cplusplus
 }

@@ -314,4 +314,56 @@ uint64_t core_float_division_mismatches(uint64_t n, uint64_t seed) {
   return bad;
 }
 
+
+// filter_discriminant for every (ray, sphere) pair, ray-major: the plain statement that the device's
+// packed routines are compared with (spheres: centre and radius, 4 floats each)
+void core_filter_values(const float *rays, size_t n_rays, const float *spheres, size_t n_spheres, float *out) {
+  std::vector<FilterSphere> fs(n_spheres);
+  for (size_t i = 0; i < n_spheres; i++) fs[i] = make_filter_sphere(spheres[4 * i], spheres[4 * i + 1], spheres[4 * i + 2], spheres[4 * i + 3]);
+  for (size_t r = 0; r < n_rays; r++) {
+    const FilterRay fr = make_filter_ray(v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]), v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]));
+    for (size_t i = 0; i < n_spheres; i++) out[r * n_spheres + i] = filter_discriminant(fr, fs[i].cx, fs[i].cy, fs[i].cz, fs[i].kprime);
+  }
+}
+
+// box_pass for every (ray, box) pair given the per-ray coefficients (9 floats: ix iy iz nx ny nz ax ay az)
+// and boxes (centre, half extents: 6 floats each)
+void core_box_pass(const float *box_ray, size_t n_rays, const float *boxes, size_t n_boxes, uint8_t *out) {
+  for (size_t r = 0; r < n_rays; r++) {
+    const float *v = box_ray + 9 * r;
+    const BoxRay br{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
+    for (size_t b = 0; b < n_boxes; b++) {
+      const float *q = boxes + 6 * b;
+      out[r * n_boxes + b] = box_pass(br, GroupBox{q[0], q[1], q[2], q[3], q[4], q[5]}) ? 1 : 0;
+    }
+  }
+}
+
+// make_box_ray as the host forms it (its reciprocal is the correctly rounded one, the device's is within one ulp)
+void core_make_box_ray(const float *rays, size_t n_rays, float sigma0, float sigma1, float *out) {
+  for (size_t r = 0; r < n_rays; r++) {
+    const BoxRay b = make_box_ray(v3(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]), v3(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]), sigma0, sigma1);
+    const float v[9] = {b.ix, b.iy, b.iz, b.nx, b.ny, b.nz, b.ax, b.ay, b.az};
+    std::memcpy(out + 9 * r, v, sizeof v);
+  }
+}
+
+// the scan layout's boxes for a scene (group boxes, then super-group boxes), 6 floats each; returns the count
+size_t core_layout_boxes(const rt_sphere *s, size_t n, float *out, size_t cap, float *sigma0, float *sigma1) {
+  const rtcluster::Layout L = rtcluster::build_layout(s, n, 512);
+  size_t k = 0;
+  for (const auto *list : {&L.boxes, &L.supers, &L.batches})
+    for (const GroupBox &b : *list) {
+      if (b.hx > 1.0e29f || b.hx < 0.0f) continue;   // "always" and "never" markers are not boxes
+      if (out && k < cap) {
+        const float v[6] = {b.cx, b.cy, b.cz, b.hx, b.hy, b.hz};
+        std::memcpy(out + 6 * k, v, sizeof v);
+      }
+      k++;
+    }
+  if (sigma0) *sigma0 = L.sigma0;
+  if (sigma1) *sigma1 = L.sigma1;
+  return k;
+}
+
 }  // extern "C"

@@ -33,14 +33,15 @@ def test_extension_handling(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_renders_the_same_bytes_as_the_library(tmp_path, renderer, rt):
+def test_cli_renders_the_bytes_of_the_oracle(tmp_path, rt, oracle):
     out = tmp_path / "o.ppm"
     p = run("-s", "final", "-x", "200", "-y", "100", "-n", "4", "-t", "2", "-o", str(out))
     assert p.returncode == 0, p.stderr
     blob = out.read_bytes()
     assert blob.startswith(b"P6\n200 100 255\n")                          # c/main.c:412
-    renderer.upload(rt.random_scene())
-    want = renderer.render_host(rt.camera_default(200, 100), rt.Job(200, 100, 4, seed=0), debug=False)["rgb8"]
+    from conftest import as_oracle_scene
+    want = oracle.render_det(rt.camera_default(200, 100).as_array(), as_oracle_scene(rt.random_scene()), 200, 100, 4, seed=0,
+                             host_threads=16, want_debug=False)["rgb8"]
     assert blob[len(b"P6\n200 100 255\n"):] == want.tobytes()
     p2 = run("-s", "final", "-x", "200", "-y", "100", "-n", "4", "-o", "-")           # '-' = stdout, c/main.c:68-70
     assert p2.returncode == 0 and hashlib.sha256(p2.stdout).digest() == hashlib.sha256(blob).digest()

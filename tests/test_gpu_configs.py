@@ -1,0 +1,115 @@
+"""The baseline configurations at their real sizes, through the C ABI, against the oracle.
+
+The oracle cannot render a 1920x1080x64 frame in test time, but it renders row bands of one
+(`render_det(row0=, rows=)`), and a job of the library is a set of row tiles: a few bands of every
+configuration at its true width, height and sample count pin the index arithmetic the full-size
+launches use (tile-major path ids, chunk stepping, the multiply-high row division of interleaved
+tiles) and the sample summation order at the sample counts of the benchmark."""
+import numpy as np
+import pytest
+
+from conftest import as_oracle_scene
+from test_gpu_parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_rows(oracle, cam, osc, nx, ny, spp, seed, row_list, max_depth=50):
+    """the oracle's outputs for the given image rows (runs of consecutive rows are rendered together)"""
+    parts = []
+    rows = list(row_list)
+    i = 0
+    while i < len(rows):
+        j = i
+        while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1:
+            j += 1
+        parts.append(oracle.render_det(cam.as_array(), osc, nx, ny, spp, max_depth=max_depth, seed=seed, row0=rows[i],
+                                       rows=j - i + 1, host_threads=16))
+        i = j + 1
+    return {k: np.concatenate([p[k] for p in parts]) for k in ("rgb8", "linear", "first_hit", "hit_sum")}
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_dense_field_render_equals_oracle(renderer, rt, oracle, flags):
+    """Baseline config 4: the 200x200 field, 40,004 spheres, streamed through LDS in 79 batches of 512 (so the
+    workgroup's batch mask uses both of its 64-bit halves), rendered by the trace kernel proper: culled
+    (batch boxes voted per workgroup) and with every sphere filtered for every ray."""
+    sc = rt.random_scene(100)
+    assert len(sc) == 40004
+    renderer.upload(sc)
+    nx, ny, spp = 96, 54, 2
+    cam = rt.camera_default(nx, ny)
+    renderer.counters(reset=True)
+    got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=17, flags=flags))
+    c = renderer.counters(reset=True)
+    want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=17, host_threads=16)
+    assert_parity(got, want)
+    assert c["paths"] == nx * ny * spp
+    if flags == 2:
+        assert c["sphere_tests"] == c["segments"] * len(sc) and c["box_tests"] == 0
+    else:
+        assert 0 < c["sphere_tests"] < c["segments"] * len(sc) // 20 and c["box_tests"] > 0
+
+
+def test_dense_field_rows_at_full_size(renderer, rt, oracle):
+    """Config 4 at 1920x1080x16: two rows of the real frame (ground rows, where rays graze thousands of spheres)."""
+    sc = rt.random_scene(100)
+    renderer.upload(sc)
+    nx, ny, spp = 1920, 1080, 16
+    cam = rt.camera_default(nx, ny)
+    job = rt.Job(nx, ny, spp, seed=0, row0=700, tile_rows=1, tile_stride=300, n_tiles=2)      # rows 700 and 1000
+    got = renderer.render_host(cam, job)
+    want = oracle_rows(oracle, cam, as_oracle_scene(sc), nx, ny, spp, 0, [700, 1000])
+    assert_parity(got, want)
+
+
+def test_final_scene_bands_at_1080p_64spp(renderer, rt, oracle):
+    """Config 2 (the benchmark's frame): 8-row bands of the 1920x1080x64 frame -- sky, horizon, spheres, the
+    bottom edge -- and one interleaved job (three tiles 64 rows apart, the multi-GPU layout)."""
+    sc = rt.random_scene()
+    renderer.upload(sc)
+    nx, ny, spp = 1920, 1080, 64
+    cam = rt.camera_default(nx, ny)
+    osc = as_oracle_scene(sc)
+    for row0 in (0, 536, 1072):
+        got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=0, row0=row0, tile_rows=8))
+        want = oracle_rows(oracle, cam, osc, nx, ny, spp, 0, range(row0, row0 + 8))
+        assert_parity(got, want)
+    import raytrace_amd as R
+    job = rt.Job(nx, ny, spp, seed=0, row0=616, tile_rows=8, tile_stride=64, n_tiles=3)
+    rows = R.job_row_indices(job)
+    assert list(rows[:9]) == list(range(616, 624)) + [680] and len(rows) == 24
+    got = renderer.render_host(cam, job)
+    want = oracle_rows(oracle, cam, osc, nx, ny, spp, 0, rows)
+    assert_parity(got, want)
+    # the last rank's job of an 8-GPU run: tiles clipped at the bottom edge of the image (1080 = 135 tiles of 8)
+    job = R.interleaved_job(nx, ny, spp, 6, 8, 8, seed=0)
+    rows = R.job_row_indices(job)
+    tail = rows[-8:]
+    part = renderer.render_host(cam, job)
+    want = oracle_rows(oracle, cam, osc, nx, ny, spp, 0, tail)
+    assert_parity({k: v[-8:] for k, v in part.items()}, want)
+
+
+def test_glass_scene_rows_at_1080p_256spp(renderer, rt, oracle):
+    """Config 5: all glass and mirrors, depth 50, 256 spp -- four rows through the spheres of the real frame."""
+    sc = rt.glass_scene()
+    renderer.upload(sc)
+    nx, ny, spp = 1920, 1080, 256
+    cam = rt.camera_default(nx, ny)
+    job = rt.Job(nx, ny, spp, seed=0, row0=640, tile_rows=2, tile_stride=200, n_tiles=2)      # rows 640-641, 840-841
+    got = renderer.render_host(cam, job)
+    want = oracle_rows(oracle, cam, as_oracle_scene(sc), nx, ny, spp, 0, [640, 641, 840, 841])
+    assert_parity(got, want)
+
+
+def test_final_scene_rows_at_4k_1024spp(renderer, rt, oracle):
+    """Config 3: 3840x2160 at 1024 spp -- two rows of the real frame as tiles of an interleaved job."""
+    sc = rt.random_scene()
+    renderer.upload(sc)
+    nx, ny, spp = 3840, 2160, 1024
+    cam = rt.camera_default(nx, ny)
+    job = rt.Job(nx, ny, spp, seed=0, row0=1199, tile_rows=1, tile_stride=960, n_tiles=2)     # rows 1199 and 2159
+    got = renderer.render_host(cam, job)
+    want = oracle_rows(oracle, cam, as_oracle_scene(sc), nx, ny, spp, 0, [1199, 2159])
+    assert_parity(got, want)

@@ -261,13 +261,12 @@ def test_image_is_independent_of_the_partition(renderer, rt):
         assert np.array_equal(img, whole["rgb8"]) and np.array_equal(lin.view(np.uint32), whole["linear"].view(np.uint32))
 
 
-def test_c_driver_gathers_tiles(rt, renderer):
-    """rth_raytrace: several contexts (wrapped onto the devices present), host gather."""
+def test_c_driver_gathers_tiles(rt, oracle):
+    """rth_raytrace: several contexts (wrapped onto the devices present), host gather; the oracle's picture."""
     sc = rt.small_scene()
     nx, ny, spp = 120, 60, 4
     cam = rt.camera_default(nx, ny)
-    renderer.upload(sc)
-    want = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=0))["rgb8"]
+    want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=0, host_threads=16, want_debug=False)["rgb8"]
     for n_dev in (1, 3):
         img, ms = rt.raytrace(cam, sc, nx, ny, spp, n_devices=n_dev, tile_rows=8)
         assert np.array_equal(img, want) and ms > 0
@@ -285,7 +284,8 @@ def test_full_size_properties(renderer, rt):
     out = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=1))
     c = renderer.counters(reset=True)
     assert c["paths"] == nx * ny * spp
-    assert c["tests"] <= c["segments"] * (len(sc) + len(sc) // 8 + 4)     # group culling: bounds + surviving groups
+    assert c["sphere_tests"] <= c["segments"] * len(sc) // 4 and c["box_tests"] <= c["segments"] * (len(sc) // 8 + 20)   # group culling
+    assert c["wave_iterations"] * 64 >= c["segments"]
     assert c["segments"] >= c["paths"] and c["candidates"] >= c["segments"] * 0.5
     sky = out["first_hit"] == -1
     assert sky[:50].all() and not sky[-200:].any()
@@ -323,8 +323,8 @@ def test_group_culling_changes_nothing_but_the_test_count(renderer, rt, scene, n
     c_full = renderer.counters(reset=True)
     cull = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=4))
     c_cull = renderer.counters(reset=True)
-    assert c_full["tests"] == c_full["segments"] * len(sc)
-    assert c_cull["segments"] == c_full["segments"] and c_cull["tests"] <= c_full["tests"] * 1.2
+    assert c_full["sphere_tests"] == c_full["segments"] * len(sc) and c_full["box_tests"] == 0
+    assert c_cull["segments"] == c_full["segments"] and c_cull["sphere_tests"] + c_cull["box_tests"] <= c_full["sphere_tests"] * 1.2
     for k in ("rgb8", "first_hit", "hit_sum"):
         assert np.array_equal(full[k], cull[k]), k
     assert np.array_equal(full["linear"].view(np.uint32), cull["linear"].view(np.uint32))

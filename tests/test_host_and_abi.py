@@ -19,12 +19,20 @@ def test_header_symbols_are_exported(rt):
     for name in declared:
         assert hasattr(lib, name), name
     assert declared <= set(rt._native.DEVICE_SYMBOLS), declared - set(rt._native.DEVICE_SYMBOLS)
-    assert rt._native.device.rt_abi_version() == 1
+    assert rt._native.device.rt_abi_version() == 2
+    m = re.search(r"#define RT_AMD_ABI_VERSION (\d+)", text)
+    assert m and int(m.group(1)) == 2
+    hdr = open(os.path.join(ROOT, "raytrace_amd", "host", "rt_host.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    host_declared = set(re.findall(r"\b(rth_[a-z_0-9]+)\s*\(", hdr))
+    hlib = C.CDLL(rt._native.HOST_LIB)
+    for name in host_declared:
+        assert hasattr(hlib, name), name
 
 
 def test_struct_layouts(rt):
     assert C.sizeof(rt._native.RtCamera) == 88 and rt.SPHERE_DTYPE.itemsize == 36
-    assert C.sizeof(rt._native.RtJob) == 48 and C.sizeof(rt._native.RtCounters) == 104
+    assert C.sizeof(rt._native.RtJob) == 52 and C.sizeof(rt._native.RtCounters) == 112
 
 
 def test_host_inputs_match_oracle(rt, oracle):
