@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 /* 2: rt_job.sample0 and RT_FLAG_PROGRESSIVE; rt_counters.tests split into sphere_tests and box_tests;
- *    the unit-level rt_debug_filter / rt_debug_box_pass / rt_debug_arith */
+ *    rt_render_device_static; the unit-level rt_debug_filter / rt_debug_box_pass / rt_debug_arith */
 #define RT_AMD_ABI_VERSION 2
 
 enum {
@@ -146,6 +146,22 @@ int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, size_t n);
 int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_job *job,
                      uint8_t *d_rgb8, float *d_linear, int32_t *d_first_hit,
                      uint32_t *d_hit_sum);
+
+/* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid it).  No counterpart in the reference.  Same arguments, same
+ * bytes; the kernels' scratch (per-path radiance, per-pixel running sums, the work-queue head, the event
+ * counts) lives in one array of RT_STATIC_SCRATCH_BYTES that the library holds statically on every GPU
+ * it runs on, so the call makes no hipMalloc/hipFree and creates nothing.  Limits: the megakernel only
+ * (RT_KERNEL_MEGA), no RT_FLAG_PROGRESSIVE, the scene uploaded beforehand, and
+ * rt_job_rows(job) * nx <= RT_STATIC_MAX_PIXELS (render larger frames in row bands); beyond that it
+ * returns RT_ERR_LIMIT.  Samples beyond what the scratch holds at once are rendered in batches.  Every
+ * call on a GPU uses that GPU's one array: calls that overlap on one GPU (two contexts, two streams)
+ * race, and rt_ctx_counters does not see this entry point's work. */
+#define RT_STATIC_SCRATCH_BYTES (32u << 20)
+#define RT_STATIC_MAX_PIXELS 700000u
+int rt_render_device_static(rt_ctx *ctx, const rt_camera *cam, const rt_job *job,
+                            uint8_t *d_rgb8, float *d_linear, int32_t *d_first_hit,
+                            uint32_t *d_hit_sum);
 
 /* The same through context-owned device buffers, then copied to HOST
  * pointers; returns when the copies are done.  This is the form the

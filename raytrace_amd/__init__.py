@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _native as N
 from ._native import (DIELECTRIC, FLAG_FULL_SCAN, FLAG_PROFILE, FLAG_PROGRESSIVE, KERNEL_MEGA, KERNEL_WAVEFRONT, MATTE, METAL,
-                      SCENE_DENSE, SCENE_FINAL, SCENE_GLASS, SCENE_SMALL, SCENE_TRIVIAL, SPHERE_DTYPE,
+                      SCENE_DENSE, SCENE_FINAL, SCENE_GLASS, SCENE_SMALL, SCENE_TRIVIAL, SPHERE_DTYPE, STATIC_MAX_PIXELS,
                       RtCamera, RtError, RtJob)
 
 __all__ = ["camera_new", "camera_default", "small_scene", "trivial_scene", "random_scene", "glass_scene",
@@ -161,11 +161,13 @@ class Renderer:
                 "rt_render_host")
         return {"rgb8": rgb, "linear": lin, "first_hit": fh, "hit_sum": hs}
 
-    def render_device(self, cam, job, d_rgb8, d_linear=0, d_first_hit=0, d_hit_sum=0):
-        """Asynchronous render into device pointers (ints, e.g. tensor.data_ptr())."""
-        N.check(N.device.rt_render_device(self._h, C.byref(cam), C.byref(job), C.c_void_p(d_rgb8),
-                                          C.c_void_p(d_linear or None), C.c_void_p(d_first_hit or None),
-                                          C.c_void_p(d_hit_sum or None)), "rt_render_device")
+    def render_device(self, cam, job, d_rgb8, d_linear=0, d_first_hit=0, d_hit_sum=0, static=False):
+        """Asynchronous render into device pointers (ints, e.g. tensor.data_ptr()).  static: through
+        rt_render_device_static, the entry point that allocates nothing."""
+        fn, name = ((N.device.rt_render_device_static, "rt_render_device_static") if static
+                    else (N.device.rt_render_device, "rt_render_device"))
+        N.check(fn(self._h, C.byref(cam), C.byref(job), C.c_void_p(d_rgb8), C.c_void_p(d_linear or None),
+                   C.c_void_p(d_first_hit or None), C.c_void_p(d_hit_sum or None)), name)
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -19,6 +19,7 @@ MATTE, METAL, DIELECTRIC = 0, 1, 2
 KERNEL_MEGA, KERNEL_WAVEFRONT = 0, 1
 FLAG_PROFILE, FLAG_FULL_SCAN, FLAG_PROGRESSIVE = 1, 2, 4
 ABI_VERSION = 2
+STATIC_SCRATCH_BYTES, STATIC_MAX_PIXELS = 32 << 20, 700000
 ARITH_SQRT_WIDENED, ARITH_DIV_WIDENED, ARITH_DIV_F32_BY, ARITH_RCP_NARROWED, ARITH_UNIT_FLOAT, ARITH_UNIT_DOUBLE = range(6)
 SCENE_SMALL, SCENE_FINAL, SCENE_DENSE, SCENE_GLASS, SCENE_TRIVIAL = 0, 1, 2, 3, 4
 
@@ -91,6 +92,8 @@ DEVICE_SYMBOLS = {
                                    C.c_void_p, C.c_void_p]),
     "rt_render_host": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtJob), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    "rt_render_device_static": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtJob), C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
     "rt_ctx_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rt_ctx_trace_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "rt_ctx_counters": (C.c_int, [C.c_void_p, C.POINTER(RtCounters), C.c_int]),

@@ -1601,6 +1601,32 @@ struct DevBuf {
 
 }  // namespace
 
+// Scratch of rt_render_device_static: one array per GPU, allocated when the code object is loaded on
+// it and held until the process ends.  On the host the name is a stand-in, not an address: rt_ctx_create
+// asks the runtime for the array's address on the context's device (static_scratch_address) and every
+// use below goes through that pointer.
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};
+
+// the address of `scratch` on `device`, which must be the current device; asked once per device
+int static_scratch_address(int device, unsigned char **out) {
+  if (device < 0 || device >= kMaxDevices) return fail(RT_ERR_LIMIT, "device index beyond the static scratch table");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) return fail(RT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+  }
+  *out = g_scratch_ptr[device];
+  return RT_OK;
+}
+}  // namespace
+
 // what a progressive render leaves behind for the call that continues it
 struct ProgressiveState {
   bool valid = false;
@@ -1612,6 +1638,7 @@ struct ProgressiveState {
 
 struct rt_ctx {
   int device = 0;
+  unsigned char *static_scratch = nullptr;   // this device's copy of `scratch`
   ProgressiveState progressive;
   unsigned long scene_generation = 0;        // bumped by every rt_scene_upload
   hipStream_t own_stream = nullptr;
@@ -1927,6 +1954,14 @@ int rt_ctx_create(int device, rt_ctx **out) {
     return fail(RT_ERR_HIP, std::string("context set-up: ") + hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  // this device's copy of the static scratch (rt_render_device_static), with the device current
+  {
+    int rc_s = static_scratch_address(device, &c->static_scratch);
+    if (rc_s != RT_OK) {
+      rt_ctx_destroy(c);
+      return rc_s;
+    }
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->num_cus = prop.multiProcessorCount;
@@ -2145,6 +2180,50 @@ int rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t
     c->progressive.scene_generation = c->scene_generation;
   }
   return rc;
+}
+
+int rt_render_device_static(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *d_rgb8, float *d_linear,
+                            int32_t *d_first_hit, uint32_t *d_hit_sum) {
+  if (!c || !cam || !d_rgb8) return fail(RT_ERR_ARG, "null argument");
+  int rc = check_job(job);
+  if (rc != RT_OK) return rc;
+  if (c->n == 0) return fail(RT_ERR_NO_SCENE, "no scene uploaded");
+  if (job->kernel != RT_KERNEL_MEGA) return fail(RT_ERR_LIMIT, "rt_render_device_static runs the megakernel only");
+  if ((job->flags & RT_FLAG_PROGRESSIVE) != 0 || job->sample0 != 0)
+    return fail(RT_ERR_LIMIT, "rt_render_device_static does not continue progressive renders");
+  const uint64_t npix64 = (uint64_t)rt_job_rows(job) * job->nx;
+  if (npix64 == 0) return fail(RT_ERR_ARG, "job covers no rows");
+  if (npix64 > RT_STATIC_MAX_PIXELS)
+    return fail(RT_ERR_LIMIT, "rt_render_device_static: " + std::to_string(npix64) + " pixels in one call, the static scratch holds " +
+                                  std::to_string(RT_STATIC_MAX_PIXELS) + " (render the frame in row bands)");
+  if (!c->static_scratch) return fail(RT_ERR_HIP, "the static scratch was not found on this device");
+  RT_HIP(hipSetDevice(c->device));
+  // carve-up of the array: [0, 256) queue head and event counts; running sums; first-hit carry; radiance
+  const uint32_t npix = (uint32_t)npix64;
+  constexpr size_t kHeader = 256;
+  static_assert(64 + kNumCounters * sizeof(unsigned long long) <= kHeader, "header too small");
+  static_assert(kHeader + (size_t)RT_STATIC_MAX_PIXELS * (2 * sizeof(float4) + sizeof(int32_t)) + 16 <= RT_STATIC_SCRATCH_BYTES,
+                "the largest job must fit with one sample per batch");
+  unsigned char *base = c->static_scratch;
+  const size_t acc_off = kHeader, fh_off = acc_off + (size_t)npix * sizeof(float4);
+  const size_t rad_off = (fh_off + (size_t)npix * sizeof(int32_t) + 15u) & ~(size_t)15u;
+  const size_t fit = (RT_STATIC_SCRATCH_BYTES - rad_off) / ((size_t)npix * sizeof(float4));
+  Workspace ws;
+  ws.batch = (uint32_t)(fit < job->nsamples ? fit : job->nsamples);
+  ws.queue = reinterpret_cast<unsigned int *>(base);
+  ws.counters = reinterpret_cast<unsigned long long *>(base + 64);
+  ws.acc = reinterpret_cast<float4 *>(base + acc_off);
+  ws.fh_acc = reinterpret_cast<int32_t *>(base + fh_off);
+  ws.rad = reinterpret_cast<float4 *>(base + rad_off);
+  // the array keeps the last call's contents: the queue head is cleared before every launch
+  // (launch_render), the counts here; sums and radiance are written before they are read
+  RT_HIP(hipMemsetAsync(base, 0, kHeader, c->stream));
+  // nothing below may create anything: the occupancy of the kernel variants was asked at scene upload
+  const bool cull_scan = (job->flags & RT_FLAG_FULL_SCAN) == 0, batched = c->n_pad > kMaxLdsSpheres;
+  const void *fn = trace_kernel_fn(batched, cull_scan, (job->flags & RT_FLAG_PROFILE) != 0);
+  if (c->blocks_per_cu.find(std::make_pair(fn, trace_lds_bytes(c->n_pad, cull_scan))) == c->blocks_per_cu.end())
+    return fail(RT_ERR_HIP, "kernel occupancy unknown (scene upload did not complete)");
+  return launch_render(c, cam, job, ws, false, d_rgb8, d_linear, d_first_hit, d_hit_sum);
 }
 
 int rt_render_host(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t *h_rgb8, float *h_linear,
