@@ -12,9 +12,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_out", "librt_oracle.so")
+ORACLE_NATIVE_SO = os.path.join(HERE, "_out", "librt_oracle_native.so")   # -march=native, built where it is timed
 REF_SO = os.path.join(HERE, "_ref", "libref_hooked.so")
 REF_BIN = os.path.join(HERE, "_ref", "ray_ref")
 REF_BIN_FINAL = os.path.join(HERE, "_ref", "ray_ref_final")
+REF_BIN_GPU = os.path.join(HERE, "_ref", "ray_ref_gpu")      # the reference CLI with render() bound to the GPU library
 
 SPHERE_DTYPE = np.dtype(
     [("center", "<f4", 3), ("radius", "<f4"), ("kind", "<i4"), ("albedo", "<f4", 3), ("param", "<f4")]
@@ -38,6 +40,9 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
     if os.path.isdir("/root/reference/c"):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        # the reference CLI bound to the GPU library (proof that the drop-in compiles): needs the product library built
+        if os.path.exists(os.path.join(os.path.dirname(HERE), "raytrace_amd", "lib", "libraytrace_amd.so")):
+            subprocess.check_call(["make", "-s", "-C", HERE, "integration"])
 
 
 _fp = C.POINTER(C.c_float)

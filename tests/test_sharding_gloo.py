@@ -62,3 +62,37 @@ def test_two_ranks_shard_and_gather(tmp_path, oracle, world, ny, tile_rows):
     got = np.load(out)
     want = oracle.render_det(oracle.camera_default(nx, ny), oracle.scene_small(), nx, ny, spp, seed=4, want_debug=False)["rgb8"]
     assert np.array_equal(got, want)
+
+
+def _launcher():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rt_launch", os.path.join(ROOT, "raytrace_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_self_launched_ranks_shard_and_gather(tmp_path, oracle, world):
+    """bench.py --gpus N without a launcher starts its own ranks (raytrace_amd/launch.py): RANK / WORLD_SIZE /
+    MASTER_* in the environment of N fresh processes, rendezvous on 127.0.0.1, exit code of the worst rank."""
+    nx, ny, spp, tile_rows = 40, 21, 2, 4
+    out = str(tmp_path / "frame.npy")
+    script = os.path.join(ROOT, "tests", "support", "gloo_rank.py")
+    cmd = [sys.executable, script, out, str(nx), str(ny), str(spp), str(tile_rows)]
+    rc = _launcher().launch_ranks(world, cmd, timeout=300)
+    assert rc == 0
+    want = oracle.render_det(oracle.camera_default(nx, ny), oracle.scene_small(), nx, ny, spp, seed=4, want_debug=False)["rgb8"]
+    assert np.array_equal(np.load(out), want)
+    # a failing rank is the launcher's exit code
+    assert _launcher().launch_ranks(2, cmd, env_extra={"RT_TEST_FAIL_RANK": "1"}, timeout=300) == 3
+
+
+def test_bench_parent_spawns_before_touching_a_gpu():
+    """The self-launch branch of bench.py runs before torch or the library is imported."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("sys.exit(self_launch(args))") < main.index("import torch")
+    launch_src = open(os.path.join(ROOT, "raytrace_amd", "launch.py")).read()
+    imports = [ln for ln in launch_src.splitlines() if ln.startswith(("import ", "from "))]
+    assert imports and all(ln.split()[1] in ("os", "socket", "subprocess", "sys", "time") for ln in imports)
