@@ -27,10 +27,17 @@ static uint32_t hook_mix32(uint32_t x) {
   return x;
 }
 
+static uint32_t hook_draw_hash(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 16; x *= 0x846ca68bu;
+  return x;
+}
+
 static double my_rand(void) {
   hook_draws++;
   if (hook_counter_mode) {
-    uint32_t bits = hook_mix32(hook_key + (hook_k++) * 0x9e3779b9u) >> 1;
+    /* the build's counter draw: 23 random bits as a 31-bit integer, then the reference's own conversion (c/rand.c:15) */
+    uint32_t bits = (hook_draw_hash(hook_key + (hook_k++) * 0x9e3779b9u) >> 9) << 8;
     return (double)bits / (double)0x7fffffff;
   }
   return ref_seq_rand();

@@ -71,9 +71,11 @@ double orc_ref_next(uint32_t *state) {
 }
 
 /* Counter generator of the deterministic mode.  Build-defined (the
- * reference has only the sequential chain above): a 32-bit avalanche
- * permutation applied to key + k*golden, top 31 bits, mapped to [0,1] by the
- * same double division as c/rand.c:15. */
+ * reference has only the sequential chain above): the per-path key is a
+ * 32-bit avalanche hash of (seed, pixel, sample); draw k is the top 23 bits of
+ * a two-round multiply-xorshift hash of key + k*golden, taken as the 31-bit
+ * integer r with its low 8 bits zero and mapped to [0,1) by the same double
+ * division as c/rand.c:15. */
 uint32_t orc_mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du;
   x ^= x >> 15; x *= 0x846ca68bu;
@@ -84,8 +86,13 @@ uint32_t orc_path_key(uint32_t seed, uint32_t pixel_index, uint32_t sample) {
   uint32_t a = orc_mix32(pixel_index + 0x9e3779b9u * seed);
   return orc_mix32(a ^ (sample * 0x85ebca6bu + 0x165667b1u));
 }
+uint32_t orc_draw_hash(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 16; x *= 0x846ca68bu;
+  return x;
+}
 uint32_t orc_ctr_bits(uint32_t key, uint32_t k) {
-  return orc_mix32(key + k * 0x9e3779b9u) >> 1;
+  return (orc_draw_hash(key + k * 0x9e3779b9u) >> 9) << 8;
 }
 double orc_ctr_uniform(uint32_t key, uint32_t k) {
   return (double)orc_ctr_bits(key, k) / (double)0x7fffffff;

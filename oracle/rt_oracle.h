@@ -55,8 +55,9 @@ double   orc_ref_next(uint32_t *state);     /* state starts at 123456789 */
 
 /* ---- counter RNG of the deterministic mode (build-defined) ---- */
 uint32_t orc_mix32(uint32_t x);
+uint32_t orc_draw_hash(uint32_t x);
 uint32_t orc_path_key(uint32_t seed, uint32_t pixel_index, uint32_t sample);
-uint32_t orc_ctr_bits(uint32_t key, uint32_t k);   /* 31-bit integer draw */
+uint32_t orc_ctr_bits(uint32_t key, uint32_t k);   /* 31-bit integer draw (23 random bits, low 8 zero) */
 double   orc_ctr_uniform(uint32_t key, uint32_t k);
 
 /* ---- host-side inputs ---- */

@@ -59,9 +59,21 @@ RT_HD V3 reflect(V3 u, V3 n) {
 
 // ---------------------------------------------------------------- generator
 //
-// Counter generator: draw k of path (seed, pixel, sample) is
-// mix32(key + k*0x9e3779b9) >> 1, a 31-bit integer r, returned as the double
-// r / 2147483647 exactly as c/rand.c:15 converts its integer.
+// Counter generator: draw k of path (seed, pixel, sample) is the 31-bit
+// integer r = (draw_hash(key + k*0x9e3779b9) >> 9) << 8 -- 23 random bits, the
+// low 8 zero -- returned as the double r / 2147483647 exactly as c/rand.c:15
+// converts its integer.  23 bits because most draws are narrowed to float at
+// once (c/vec.c:68), where r / 2147483647 for such an r IS m * 2^-23 (m = r >>
+// 8): the quotient exceeds m * 2^-23 by a relative 2^-31, far inside half a
+// float ulp of a 23-bit significand, so the narrowing needs no double
+// arithmetic at all (checked for every m by the host tests).
+//
+// draw_hash is two multiply-xorshift rounds; its top 23 bits are what the
+// draw uses, so the closing xorshift of a full avalanche hash (which only
+// touches the low half) is left out, and both xorshifts are by 16, one
+// instruction each on the device.  On triples of consecutive draws (the
+// unit-ball points) its statistics are those of the full-avalanche mix32
+// below, which still makes the per-path keys.
 
 RT_HD uint32_t mix32(uint32_t x) {
   x ^= x >> 16;
@@ -75,6 +87,14 @@ RT_HD uint32_t mix32(uint32_t x) {
 RT_HD uint32_t path_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
   uint32_t a = mix32(pixel + 0x9e3779b9u * seed);
   return mix32(a ^ (sample * 0x85ebca6bu + 0x165667b1u));
+}
+
+RT_HD uint32_t draw_hash(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 16;
+  x *= 0x846ca68bu;
+  return x;
 }
 
 // r / (2^31 - 1) correctly rounded to double without a division:
@@ -96,25 +116,29 @@ RT_HD double unit_from_bits(uint32_t r31) {
 // 2^31 values.
 RT_HD float unit_float_from_bits(uint32_t r31) { return (float)((double)r31 * 0x1.00000002p-31); }
 
+// the stream of one path: the hash input of its next draw, key + k * 0x9e3779b9 after k draws
 struct Rng {
-  uint32_t key;
-  uint32_t k;
+  uint32_t x;
 };
+RT_HD Rng rng_at(uint32_t key, uint32_t k = 0u) { return Rng{key + k * 0x9e3779b9u}; }
 
-// the 31 bits of the draw whose hash input is x = key + k * 0x9e3779b9
-RT_HD uint32_t bits_at(uint32_t x) {
-  x = mix32(x);
+// the 31-bit integer of the draw whose hash input is x = key + k * 0x9e3779b9
+RT_HD uint32_t bits_at(uint32_t x) { return (draw_hash(x) >> 9) << 8; }
+
+// (float)(r / (2^31 - 1)) + 1 for that draw, i.e. 1 + m * 2^-23: the 23 bits are the significand of a float
+// in [1, 2) (one funnel shift on the device)
+RT_HD float one_plus_unit_at(uint32_t x) {
+  const uint32_t h = draw_hash(x);
 #ifdef __HIP_DEVICE_COMPILE__
-  // keep mix32's last step (one instruction with a 16-bit operand select) apart from the shift below;
-  // merged, the two become (x >> 17) ^ (x >> 1), three instructions
-  asm("" : "+v"(x));
+  return __builtin_bit_cast(float, __builtin_amdgcn_alignbit(0x7fu, h, 9u));
+#else
+  return __builtin_bit_cast(float, 0x3f800000u | (h >> 9));
 #endif
-  return x >> 1;
 }
 
 RT_HD uint32_t next_bits(Rng &g) {
-  const uint32_t r = bits_at(g.key + g.k * 0x9e3779b9u);
-  g.k++;
+  const uint32_t r = bits_at(g.x);
+  g.x += 0x9e3779b9u;
   return r;
 }
 
@@ -128,18 +152,17 @@ RT_HD double next_uniform(Rng &g) { return unit_from_bits(next_bits(g)); }
 // one attempt from the three draws whose hash inputs are x, x + w, x + 2w (w = 0x9e3779b9): the
 // candidate, and whether the loop would keep it
 RT_HD bool unit_ball_try_at(uint32_t x, V3 &u) {
-  float ux = unit_float_from_bits(bits_at(x));
-  float uy = unit_float_from_bits(bits_at(x + 0x9e3779b9u));
-  float uz = unit_float_from_bits(bits_at(x + 2u * 0x9e3779b9u));
-  // 2*x - 1 (c/vec.c:67-68): the product is exact, so one fused operation rounds like the two
-  u = v3(rt_fma(2.0f, ux, -1.0f), rt_fma(2.0f, uy, -1.0f), rt_fma(2.0f, uz, -1.0f));
+  const float fx = one_plus_unit_at(x), fy = one_plus_unit_at(x + 0x9e3779b9u), fz = one_plus_unit_at(x + 2u * 0x9e3779b9u);
+  // 2*u - 1 (c/vec.c:67-68) with u = f - 1 a multiple of 2^-23: 2f - 3, exact (a multiple of 2^-22 below 1 in
+  // magnitude), hence the value the reference's two roundings give
+  u = v3(rt_fma(2.0f, fx, -3.0f), rt_fma(2.0f, fy, -3.0f), rt_fma(2.0f, fz, -3.0f));
   float s = u.x * u.x + u.y * u.y + u.z * u.z;
   return s < 1.0f && !(s < 1.4210854715202004e-14f);   // 2^-46
 }
 
 RT_HD bool unit_ball_try(Rng &g, V3 &u) {
-  const bool keep = unit_ball_try_at(g.key + g.k * 0x9e3779b9u, u);
-  g.k += 3;
+  const bool keep = unit_ball_try_at(g.x, u);
+  g.x += 3u * 0x9e3779b9u;
   return keep;
 }
 

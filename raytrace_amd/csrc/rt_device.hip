@@ -935,7 +935,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   uint32_t depth = 0, out_index = 0;
   int32_t first_hit = -1;
   V3 A = v3(0, 0, 0), B = v3(0, 0, 1), color = v3(1, 1, 1);
-  Rng g{0u, 0u};
+  Rng g{0u};
   // event counts of the wave, kept on the scalar unit (ballot popcounts and wave-uniform values)
   // (a launch has fewer than 2^32 paths and a path at most max_depth segments, shared among thousands of waves: the
   // per-wave counts of paths, segments, candidates and trips fit 32 bits; the test counts may not)
@@ -1071,8 +1071,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
         if (col < jb.nx && lrow < geo.rows) {
           const uint32_t grow = global_row(jb, lrow, geo.tile_rows_magic);
           const uint32_t sample = geo.sample0 + s_local;
-          g.key = path_key(jb.seed, grow * jb.nx + col, sample);   // keyed by the global pixel
-          g.k = 0;
+          g = rng_at(path_key(jb.seed, grow * jb.nx + col, sample));   // keyed by the global pixel
           pixel_xy_by(col, jb.ny - 1u - grow, jb.nx, jb.ny, geo.inv_nx, geo.inv_ny, g, p.x, p.y);  // rows below = j-1 of c/main.c:466
           color = v3(1.0f, 1.0f, 1.0f);
           depth = 0;
@@ -1091,7 +1090,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
     if (pending != kNone) ball = unit_ball(g);
 #if RT_EXP == 14   // the rejection loop a second time, from a generator state that gives other trip counts
     if (pending != kNone) {
-      Rng g2{g.key ^ 0x5bd1e995u, g.k};
+      Rng g2{g.x ^ 0x5bd1e995u};
       const V3 b2 = unit_ball(g2);
       asm volatile("" ::"v"(b2.x), "v"(b2.y), "v"(b2.z));
     }
@@ -1243,7 +1242,7 @@ struct WfPool {
   float4 *org;     // {A.xyz, t of the hit}
   float4 *dir;     // {B.xyz, hit index bits}
   float4 *col;     // {colour rgb, first-hit index bits}
-  uint4 *misc;     // {rng key, rng k, depth, out_index};  out_index == kWfDead: free slot
+  uint4 *misc;     // {rng stream position, unused, depth, out_index};  out_index == kWfDead: free slot
   uint32_t *qlist; // 4 queues of up to `slots` slot ids
   uint32_t *ctrl;  // [0] next item, [1..4] queue counts, [5] paths finished
   uint32_t slots;
@@ -1291,7 +1290,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_generate(const TraceArgs arg
     const uint32_t col = tx * 8u + (l & 7u), lrow = ty * 8u + (l >> 3);
     if (col >= job.nx || lrow >= args.geo.rows) continue;   // off-image id: the slot stays free
     const uint32_t grow = global_row(job, lrow);
-    Rng g{path_key(job.seed, grow * job.nx + col, args.geo.sample0 + s_local), 0u};
+    Rng g = rng_at(path_key(job.seed, grow * job.nx + col, args.geo.sample0 + s_local));
     float x, y;
     pixel_xy(col, job.ny - 1u - grow, job.nx, job.ny, g, x, y);
     V3 A, B;
@@ -1299,7 +1298,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_generate(const TraceArgs arg
     pool.org[slot] = make_float4(A.x, A.y, A.z, 0.0f);
     pool.dir[slot] = make_float4(B.x, B.y, B.z, __int_as_float(-1));
     pool.col[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(-1));
-    pool.misc[slot] = make_uint4(g.key, g.k, 0u, s_local * (args.geo.rows * job.nx) + lrow * job.nx + col);
+    pool.misc[slot] = make_uint4(g.x, 0u, 0u, s_local * (args.geo.rows * job.nx) + lrow * job.nx + col);
   }
 }
 
@@ -1398,11 +1397,11 @@ __global__ __launch_bounds__(kBlockThreads) void wf_shade(const TraceArgs args, 
       V3 p = A + o.w * B;
       V3 n = (p - v3(e.x, e.y, e.z)) / e.w;
       Material m{Q - 1, v3(m4.x, m4.y, m4.z), m4.w};
-      Rng g{mi.x, mi.y};
+      Rng g{mi.x};
       V3 atten, nA, nB;
       if (scatter(m, A, B, p, n, g, atten, nA, nB)) {
         color = atten * color;
-        mi.y = g.k;
+        mi.x = g.x;
         mi.z += 1u;
         finished = mi.z >= args.geo.job.max_depth;
         if (!finished) {
@@ -1460,7 +1459,7 @@ __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene 
 __global__ void uniforms_kernel(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double *out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Rng g{path_key(seed, pixel, sample), i};
+  Rng g = rng_at(path_key(seed, pixel, sample), i);
   out[i] = next_uniform(g);
 }
 

@@ -19,7 +19,7 @@ using namespace rtcore;
 extern "C" {
 
 void core_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, size_t n, double *out) {
-  Rng g{path_key(seed, pixel, sample), 0};
+  Rng g = rng_at(path_key(seed, pixel, sample));
   for (size_t i = 0; i < n; i++) out[i] = next_uniform(g);
 }
 
@@ -190,7 +190,7 @@ void core_render(const rt_camera *cam_in, const rt_sphere *s, size_t n, uint32_t
       int32_t fh0 = -1;
       uint32_t hsum = 0;
       for (uint32_t sample = 0; sample < nsamples; sample++) {
-        Rng g{path_key(seed, pixel, sample), 0};
+        Rng g = rng_at(path_key(seed, pixel, sample));
         float x, y;
         pixel_xy(col, up, nx, ny, g, x, y);
         V3 A, B;
@@ -364,6 +364,26 @@ size_t core_layout_boxes(const rt_sphere *s, size_t n, float *out, size_t cap, f
   if (sigma0) *sigma0 = L.sigma0;
   if (sigma1) *sigma1 = L.sigma1;
   return k;
+}
+
+
+// A draw has 23 random bits: r = m << 8.  For every m: the reference's conversion narrowed to float,
+// (float)((double)r / 2147483647.0) (c/rand.c:15 then c/vec.c:68), is exactly m * 2^-23, and the unit-ball
+// coordinate 2*u - 1 formed in two float roundings equals the kernels' single 2*(1 + m * 2^-23) - 3.
+uint64_t core_draw23_mismatches(void) {
+  uint64_t bad = 0;
+  for (uint32_t m = 0; m < (1u << 23); m++) {
+    const uint32_t r = m << 8;
+    const float ref_u = (float)((double)r / 2147483647.0);
+    const float mine = (float)m * 1.1920928955078125e-07f;   // m * 2^-23, exact
+    if (memcmp(&ref_u, &mine, 4) != 0) bad++;
+    const float ref_c = 2.0f * ref_u - 1.0f;
+    const float f = __builtin_bit_cast(float, 0x3f800000u | m);
+    const float got_c = rt_fma(2.0f, f, -3.0f);
+    if (memcmp(&ref_c, &got_c, 4) != 0) bad++;
+    if (unit_float_from_bits(r) != ref_u) bad++;
+  }
+  return bad;
 }
 
 }  // extern "C"

@@ -128,3 +128,10 @@ def test_draw_conversion_is_the_division_for_every_draw(core):
 def test_division_by_a_reused_float_divisor(core):
     core.core_float_division_mismatches.restype = C.c_uint64
     assert core.core_float_division_mismatches(C.c_uint64(20_000_000), C.c_uint64(3)) == 0
+
+
+def test_a_23_bit_draw_narrows_to_float_without_double_arithmetic(core):
+    """Draws carry 23 random bits (r = m << 8): the reference's (float)(r / (2^31 - 1)) is then m * 2^-23 and its
+    2u - 1 is the kernels' one fused operation on the float 1 + m * 2^-23, for all 2^23 values of m."""
+    core.core_draw23_mismatches.restype = C.c_uint64
+    assert core.core_draw23_mismatches() == 0
