@@ -99,6 +99,15 @@ typedef struct {
  * camera change and refines while the camera rests needs (rs/src/gui.rs:164-172, 340-357). */
 #define RT_FLAG_PROGRESSIVE 4u
 
+/* Renders on one context are pipelined: the trace kernels run on two internal streams in turn, each sample
+ * batch's resolve waits for its trace on the context's stream, so the next batch's (or the next render's) trace
+ * kernel starts while the last waves of this one are still finishing and while this one's resolve runs.  Outputs
+ * are complete in stream order on the context's stream as always.  RT_FLAG_SERIAL runs every kernel of the call
+ * on the context's stream instead, one after the other: the form to time a kernel alone (rt_ctx_trace_ms brackets
+ * the trace kernel with events on the stream it runs on, and a pipelined launch spends part of that time waiting
+ * for compute units behind the launch before it). */
+#define RT_FLAG_SERIAL 8u
+
 /* Device-side event counts accumulated by the kernels since the last reset. */
 typedef struct {
   uint64_t paths;           /* camera paths finished                            */
@@ -113,6 +122,9 @@ typedef struct {
   uint64_t cycles_scan, cycles_drain, cycles_shade, cycles_total; /* shader clocks */
   uint64_t realtime_total;       /* the waves' lifetimes in 100 MHz ticks: shader clock = cycles_total / realtime_total * 100 MHz */
   uint64_t own_groups, wave_groups; /* summed over live lanes and segments: sphere groups the lane's own ray needed / its wave scanned */
+  /* when the first and the last wave of the trace kernels since the reset started and ended, in 100 MHz ticks of the
+   * device's constant clock: how long the launch ramps up and how long its tail is */
+  uint64_t first_wave_start, last_wave_start, first_wave_end, last_wave_end;
 } rt_counters;
 
 typedef struct rt_ctx rt_ctx;
@@ -218,6 +230,9 @@ int rt_debug_box_pass(rt_ctx *ctx, const float *rays, size_t n_rays, const float
 enum { RT_ARITH_SQRT_WIDENED = 0, RT_ARITH_DIV_WIDENED = 1, RT_ARITH_DIV_F32_BY = 2, RT_ARITH_RCP_NARROWED = 3,
        RT_ARITH_UNIT_FLOAT = 4, RT_ARITH_UNIT_DOUBLE = 5 };
 int rt_debug_arith(rt_ctx *ctx, int op, const double *a, const double *b, size_t n, double *out);
+/* After a render with RT_FLAG_PROFILE: one word per wave of the trace kernel's grid (the first n, at most 16384), its
+ * lifetime in 100 MHz ticks << 24 | its trips of the bounce loop -- for diagnosing the tail of a launch. */
+int rt_debug_wave_log(rt_ctx *ctx, uint64_t *out, size_t n);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from ._native import (DIELECTRIC, FLAG_FULL_SCAN, FLAG_PROFILE, FLAG_PROGRESSIVE, KERNEL_MEGA, KERNEL_WAVEFRONT, MATTE, METAL,
+from ._native import (DIELECTRIC, FLAG_FULL_SCAN, FLAG_PROFILE, FLAG_PROGRESSIVE, FLAG_SERIAL, KERNEL_MEGA, KERNEL_WAVEFRONT, MATTE, METAL,
                       SCENE_DENSE, SCENE_FINAL, SCENE_GLASS, SCENE_SMALL, SCENE_TRIVIAL, SPHERE_DTYPE, STATIC_MAX_PIXELS,
                       RtCamera, RtError, RtJob)
 

@@ -17,7 +17,7 @@ assert SPHERE_DTYPE.itemsize == 36
 
 MATTE, METAL, DIELECTRIC = 0, 1, 2
 KERNEL_MEGA, KERNEL_WAVEFRONT = 0, 1
-FLAG_PROFILE, FLAG_FULL_SCAN, FLAG_PROGRESSIVE = 1, 2, 4
+FLAG_PROFILE, FLAG_FULL_SCAN, FLAG_PROGRESSIVE, FLAG_SERIAL = 1, 2, 4, 8
 ABI_VERSION = 2
 STATIC_SCRATCH_BYTES, STATIC_MAX_PIXELS = 32 << 20, 700000
 ARITH_SQRT_WIDENED, ARITH_DIV_WIDENED, ARITH_DIV_F32_BY, ARITH_RCP_NARROWED, ARITH_UNIT_FLOAT, ARITH_UNIT_DOUBLE = range(6)
@@ -54,7 +54,8 @@ class RtJob(C.Structure):
 class RtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("paths", "segments", "sphere_tests", "box_tests", "candidates", "wave_iterations",
                                           "live_lane_iterations", "cycles_scan", "cycles_drain", "cycles_shade",
-                                          "cycles_total", "realtime_total", "own_groups", "wave_groups")]
+                                          "cycles_total", "realtime_total", "own_groups", "wave_groups", "first_wave_start",
+                                          "last_wave_start", "first_wave_end", "last_wave_end")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -104,6 +105,7 @@ DEVICE_SYMBOLS = {
     "rt_debug_box_pass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_debug_arith": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rt_debug_wave_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
 HOST_SYMBOLS = {

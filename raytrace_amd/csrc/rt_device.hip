@@ -61,6 +61,20 @@ using namespace rtcore;
     if (RT_EXP == N && kProfile) c_drain += tick() - stage_t0_##N; \
   } while (0)
 
+// RT_EXP 35..38: the profiling build's "drain" column shows one stage of the scan instead (35 ray set-up,
+// 36 super-group boxes, 37 group-box rounds without the filter passes they trigger, 38 filter passes)
+#define RT_SCAN_STAGE (RT_EXP >= 35 && RT_EXP <= 38)
+#define RT_HSTAGE_BEGIN(N) const unsigned long long hstage_t0_##N = (RT_EXP == N) ? tick() : 0ull
+#define RT_HSTAGE_END(N) \
+  do {                   \
+    if (RT_EXP == N) h.drain_cycles += tick() - hstage_t0_##N; \
+  } while (0)
+#define RT_HSTAGE_EXCLUDE_BEGIN(N) const unsigned long long hstage_x0_##N = (RT_EXP == N) ? tick() : 0ull
+#define RT_HSTAGE_EXCLUDE_END(N) \
+  do {                           \
+    if (RT_EXP == N) h.drain_cycles -= tick() - hstage_x0_##N; \
+  } while (0)
+
 namespace {
 
 // ----------------------------------------------------------------- limits
@@ -74,7 +88,8 @@ constexpr uint32_t kMaxLdsSpheres = RT_MAX_RESIDENT;  // scan positions of a sce
 constexpr uint32_t kBatchSpheres = 512;    // larger scenes: scan positions per staged batch (the LDS footprint of
                                            // a batch is that of the reference's final scene)
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
-constexpr int kNumCounters = 14;
+constexpr int kNumCounters = 18;
+constexpr int kWaveLogBase = 32, kWaveLogEntries = 16384;   // profiling builds: one word per wave behind the counters
 constexpr int kBoxTestCounter = 13;   // (the others are numbered where rt_ctx_counters reads them)
 
 // The scan's arrays are in SCAN order (rt_cluster.h): position -> sphere, pads included.
@@ -506,6 +521,8 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
 // to the (lane, sphere) list under the owner's name.
 __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const float4 *lds_pairs, const uint8_t *lds_real8,
                                                     uint32_t base, WaveScan &w, HitState &h) {
+  RT_HSTAGE_BEGIN(38);
+  RT_HSTAGE_EXCLUDE_BEGIN(37);
   uint32_t width = 64u;   // pairs per pass
   for (uint32_t e0 = 0; e0 < w.pcnt;) {
     const uint32_t e = e0 + w.lane;
@@ -578,6 +595,8 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
     width = 64u;
   }
   w.pcnt = 0;
+  RT_HSTAGE_EXCLUDE_END(37);
+  RT_HSTAGE_END(38);
 }
 
 // Scan `count` spheres (a multiple of kDrainEvery = two groups) whose pair
@@ -641,12 +660,15 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
   // most 2048 / 32 = 64 super-groups.
   constexpr uint32_t kPairSpan = 4u * kDrainEvery;   // spheres per pair of super-groups
   unsigned long long touched = 0ull;
+  RT_HSTAGE_BEGIN(36);
   {
     auto test_pair = [&](const float4 (&sq)[3], uint32_t pair_index) {
       bool spass[2];
       box_pair(br, sq, spass);
       const unsigned long long s0 = (__ballot(spass[0]) & live_mask) | all_mask, s1 = (__ballot(spass[1]) & live_mask) | all_mask;
-      touched |= (unsigned long long)((s0 != 0ull ? 1u : 0u) | (s1 != 0ull ? 2u : 0u)) << (2u * pair_index);
+      // (two scalar selects; written as (s0 != 0 ? 1 : 0) the first one goes through a vector register)
+      const unsigned long long bit = 1ull << (2u * pair_index);
+      touched |= (s0 != 0ull ? bit : 0ull) | (s1 != 0ull ? bit << 1 : 0ull);
     };
     const uint32_t n_pairs = count / kPairSpan;
     float4 sa[3] = {lds_sboxes[0], lds_sboxes[1], lds_sboxes[2]}, sb[3];
@@ -664,6 +686,8 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     }
     tests += 2u * n_pairs;
   }
+  RT_HSTAGE_END(36);
+  RT_HSTAGE_BEGIN(37);
   // then the two rounds (four group boxes) of every super-group that was touched, the boxes of a round
   // read while the round before it is worked on (two register sets, no copies)
   if (touched != 0ull) {
@@ -714,6 +738,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
       sg = next_sg;
     }
   }
+  RT_HSTAGE_END(37);
   filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);   // (the pairs name groups of this batch)
   h.box_tests += tests;
 }
@@ -726,6 +751,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
 template <bool kBatched, bool kCull, bool kProfile = false>
 __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const ScanLds &lds, uint32_t tid, bool alive,
                                                   V3 A, V3 B, float tmin, float tmax, HitState &h) {
+  RT_HSTAGE_BEGIN(35);
   const FilterRay f = alive ? make_filter_ray(A, B) : dead_ray();
   const FilterRayP fr = pack_ray(f);   // (the culled scan rebuilds it from the wave's ray table instead)
   const BoxRayP br = pack_box_ray(make_box_ray(A, B, sc.sigma0, sc.sigma1));
@@ -758,6 +784,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
     asm volatile("" : "+v"(no_hit_hi), "+v"(no_hit_lo));
     lds.best[tid] = ((unsigned long long)no_hit_hi << 32) | no_hit_lo;
   }
+  RT_HSTAGE_END(35);
   if (kBatched) {
     // Which batches to stage: those whose box some ray of the workgroup can touch.  Every lane tests
     // its ray against every batch box (two per packed evaluation, the boxes read through the scalar
@@ -821,9 +848,9 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
     scan_batch<kCull>(sc, lds, 0u, kCull ? sc.n_pad : sc.n_full, fr, br, alive, uncullable, w, h);
   }
   if (!kCull) h.scan_tests += sc.n;
-  const unsigned long long d0 = kProfile ? tick() : 0ull;
+  const unsigned long long d0 = (kProfile && !RT_SCAN_STAGE) ? tick() : 0ull;
   drain_wave(sc, w, h);
-  if (kProfile) h.drain_cycles = tick() - d0;
+  if (kProfile && !RT_SCAN_STAGE) h.drain_cycles = tick() - d0;
   const unsigned long long key = lds.best[tid];
   const float t = __uint_as_float((uint32_t)(key >> 32));
   if (alive && t < tmax) {
@@ -852,6 +879,8 @@ __device__ __forceinline__ uint32_t global_row(const rt_job &job, uint32_t lr, u
 // the fourth word); resolve_kernel then adds each pixel's samples in sample
 // order, which is the reference's summation order (c/main.c:462-469).
 constexpr uint32_t kChunkItems = 512;
+constexpr uint32_t kTailChunkItems = 64;      // chunk size for the last paths of a launch
+constexpr uint32_t kTailPathsPerLane = 4;     // how many paths per lane of the grid are handed out in small chunks
 
 // image and queue geometry of a launch: what handing out new paths needs
 struct PathGeom {
@@ -861,6 +890,8 @@ struct PathGeom {
   uint32_t sample0;       // first sample of this batch
   uint32_t batch;         // SB: samples in this batch
   uint32_t total_items;   // tiles * SB * 64
+  uint32_t last_tile_row; // ceil(rows / 8) - 1
+  uint32_t big_end;       // ids below this (a multiple of kChunkItems) go out in large chunks, the rest in small ones
   uint32_t tile_rows_magic;  // see global_row
   double inv_nx, inv_ny;  // 1.0 / (double)(float)nx, ny (pixel_xy_by)
 };
@@ -879,7 +910,7 @@ struct TraceArgs {
   PathGeom geo;
   DeviceScene sc;
   float4 *rad;            // [SB][rows*nx] {r, g, b, first-hit index bits}
-  unsigned int *queue;    // next unclaimed item id
+  unsigned int *queue;    // two words: next unclaimed id of the large chunks, and of the small ones (less big_end)
   unsigned long long *counters;
 };
 
@@ -925,7 +956,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   }
 
   // wave-uniform queue state
-  uint32_t pool_next = 0, pool_end = 0;
+  uint32_t pool_next = 0, pool_end = 0, take = kChunkItems;
   // where the chunk in hand starts: its first (tile, sample) index and that index split into tile, sample
   // and the tile into row and column of tiles -- one set of divisions per chunk instead of per path
   uint32_t pool_ts0 = 0, pool_tile0 = 0, pool_s0 = 0, pool_ty0 = 0, pool_tx0 = 0;
@@ -1030,18 +1061,31 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
       const PathGeom geo = kernarg_now<PathGeom>(offsetof(TraceArgs, geo));
       const rt_job &jb = geo.job;
       if (pool_next == pool_end) {
-        uint32_t base = 0;
-        if (lane == 0) {
-          unsigned int take = kChunkItems;
-          asm volatile("" : "+v"(take));   // (not a loop invariant held in a vector register)
-          base = atomicAdd(kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)), take);
+        // Ids below geo.big_end are handed out kChunkItems at a time from the first queue word; the last
+        // few paths per lane of the launch, 64 at a time from the second: a wave that takes the last large
+        // chunk would otherwise still be at work on it long after the others have left (the launch ended
+        // with a tenth of its duration spent waiting for such waves).
+        uint32_t base = 0, limit = geo.big_end;
+        for (;;) {   // (two turns on the trip that finds the large chunks gone)
+          if (lane == 0) {
+            unsigned int amount = take;
+            asm volatile("" : "+v"(amount));   // (not a loop invariant held in a vector register)
+            base = atomicAdd(kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)) + (take == kChunkItems ? 0 : 1), amount);
+          }
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (take != kChunkItems) {
+            base += geo.big_end;
+            limit = geo.total_items;
+            break;
+          }
+          if (base < geo.big_end) break;
+          take = kTailChunkItems;
         }
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= geo.total_items) {
+        if (base >= limit) {
           exhausted = true;
         } else {
           pool_next = base;
-          pool_end = min(base + kChunkItems, geo.total_items);
+          pool_end = min(base + take, limit);
           pool_ts0 = base >> 6;
           pool_tile0 = pool_ts0 / geo.batch;
           pool_s0 = pool_ts0 - pool_tile0 * geo.batch;
@@ -1067,7 +1111,10 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
           tx -= geo.tiles_x;
           ty++;
         }
-        const uint32_t col = tx * 8u + (l & 7u), lrow = ty * 8u + (l >> 3);
+        // Rows of tiles are taken from the bottom of the job upwards: the paths of a launch that are handed out
+        // last decide how long its waves go on after the queue is empty, and in pictures with the sky on
+        // top those are then the shortest paths instead of the longest.
+        const uint32_t col = tx * 8u + (l & 7u), lrow = (geo.last_tile_row - ty) * 8u + (l >> 3);
         if (col < jb.nx && lrow < geo.rows) {
           const uint32_t grow = global_row(jb, lrow, geo.tile_rows_magic);
           const uint32_t sample = geo.sample0 + s_local;
@@ -1127,7 +1174,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
     if (kProfile) {
       unsigned long long c3 = tick();
       c_scan += c1 - c0;
-#if RT_EXP < 31 || RT_EXP > 39
+#if RT_EXP < 31 || RT_EXP > 34
       c_drain += c2 - c1;
 #endif
       c_shade += c3 - c2;
@@ -1148,7 +1195,16 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
     atomicAdd(&args.counters[7], c_drain);
     atomicAdd(&args.counters[8], c_shade);
     atomicAdd(&args.counters[9], __builtin_amdgcn_s_memtime() - c_begin);
-    atomicAdd(&args.counters[10], __builtin_amdgcn_s_memrealtime() - r_begin);
+    const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+    atomicAdd(&args.counters[10], r_end - r_begin);
+    // when the first and the last wave started and ended (100 MHz ticks of the device's constant clock)
+    atomicMin(&args.counters[14], r_begin);
+    atomicMax(&args.counters[15], r_begin);
+    atomicMin(&args.counters[16], r_end);
+    atomicMax(&args.counters[17], r_end);
+    // this wave's lifetime (ticks) and trips, for the tail diagnosis
+    const uint32_t wave_id = blockIdx.x * (kBlockThreads / 64) + (tid >> 6);
+    if (wave_id < (uint32_t)kWaveLogEntries) args.counters[kWaveLogBase + wave_id] = ((r_end - r_begin) << 24) | (unsigned long long)(n_iter & 0xffffffu);
   }
   if (kProfile) {
     unsigned long long w_own = wave_sum(n_own), w_wave = wave_sum(n_wave);
@@ -1188,9 +1244,7 @@ struct ResolveArgs {
   uint32_t *hit_sum;
 };
 
-__global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs args) {
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= args.npix) return;
+__device__ __forceinline__ void resolve_pixel(const ResolveArgs &args, uint32_t p) {
   V3 sum = v3(0.0f, 0.0f, 0.0f);
   uint32_t hsum = 0;
   int32_t fh0 = -1;
@@ -1226,6 +1280,11 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs args) {
   if (args.first_hit) args.first_hit[p] = fh0;
   if (args.hit_sum) args.hit_sum[p] = hsum;
 }
+
+__global__ __launch_bounds__(256) void resolve_kernel(const ResolveArgs args) {
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < args.npix; p += gridDim.x * 256u) resolve_pixel(args, p);
+}
+
 
 // ---------------------------------------------------------------------------
 // Material-sorted wavefront variant (RT_KERNEL_WAVEFRONT).  Same arithmetic,
@@ -1641,6 +1700,16 @@ struct rt_ctx {
   ProgressiveState progressive;
   unsigned long scene_generation = 0;        // bumped by every rt_scene_upload
   hipStream_t own_stream = nullptr;
+  // The trace kernels run on a stream of their own and each sample batch's resolve waits for its trace on the
+  // context's stream: the trace of the next batch (or of the next render) overlaps the resolve of this one, which
+  // is bound by HBM where the trace is bound by the vector ALUs.  Two radiance buffers alternate.
+  hipStream_t trace_stream[2] = {nullptr, nullptr};   // (two, alternating like the buffers: the next batch's trace
+                                                      // kernel fills the compute units as this one's last waves leave)
+  hipEvent_t ev_traced[2] = {nullptr, nullptr}, ev_resolved[2] = {nullptr, nullptr};
+  bool resolved_recorded[2] = {false, false};
+  bool last_render_piped = true;     // else the trace stream has to wait for the context's stream once
+  hipEvent_t ev_handover = nullptr;
+  unsigned long batches_launched = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the whole of the last render
   bool timed = false;
@@ -1659,7 +1728,7 @@ struct rt_ctx {
   float sigma0 = 0.0f, sigma1 = 0.0f;
   DevBuf<unsigned long long> counters;
   DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
-  DevBuf<float4> rad;                // per-path radiance of one sample batch
+  DevBuf<float4> rad[2];             // per-path radiance of one sample batch (two: see trace_stream)
   DevBuf<float4> acc;                // running per-pixel sums between batches
   DevBuf<int32_t> fh_acc;
   int num_cus = 256;
@@ -1757,7 +1826,9 @@ int run_wavefront_batch(rt_ctx *c, const TraceArgs &t, uint32_t valid_paths, boo
 
 // Device memory one render works in, beyond its inputs and outputs.
 struct Workspace {
-  float4 *rad;               // per-path radiance of one sample batch: batch * npix entries
+  float4 *rad[2];            // per-path radiance of one sample batch: batch * npix entries each; batches alternate
+                             // between the two when the render is pipelined, else only rad[0] is used
+  bool pipelined;            // trace kernels on the context's trace stream (see rt_ctx::trace_stream)
   float4 *acc;               // running per-pixel sums between batches (needed when batch < nsamples or progressive)
   int32_t *fh_acc;
   unsigned int *queue;       // work-queue head of the trace kernel
@@ -1808,8 +1879,9 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Work
   t.geo.job = *job;
   t.geo.rows = rows;
   t.geo.tiles_x = tiles_x;
+  t.geo.last_tile_row = tiles_y - 1u;
   t.sc = scene_view(c);
-  t.rad = ws.rad;
+  t.rad = ws.rad[0];
   t.queue = ws.queue;
   t.counters = ws.counters;
   const bool cull_scan = (job->flags & RT_FLAG_FULL_SCAN) == 0;
@@ -1826,7 +1898,16 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Work
   const int slot = (int)(c->renders % rt_ctx::kHistory);
   auto &pairs = c->trace_events[slot];
   int used = 0;
-  if (record) RT_HIP(hipEventRecord(c->ev_begin, c->stream));
+  const bool piped_render = ws.pipelined && job->kernel == RT_KERNEL_MEGA;
+  const bool own_buffers = ws.rad[1] != nullptr;     // the context's buffers (not the static scratch)
+  if (piped_render && !c->last_render_piped) {
+    // the render before ran wholly on the context's stream and shared the queue head and the counters
+    RT_HIP(hipEventRecord(c->ev_handover, c->stream));
+    RT_HIP(hipStreamWaitEvent(c->trace_stream[0], c->ev_handover, 0));
+    RT_HIP(hipStreamWaitEvent(c->trace_stream[1], c->ev_handover, 0));
+  }
+  if (own_buffers) c->last_render_piped = piped_render;
+  if (record) RT_HIP(hipEventRecord(c->ev_begin, piped_render ? c->trace_stream[c->batches_launched & 1u] : c->stream));
   for (uint32_t s0 = 0; s0 < job->nsamples; s0 += batch) {
     if (record && (int)pairs.size() <= used) {
       hipEvent_t e0, e1;
@@ -1843,20 +1924,36 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Work
                             ? (uint32_t)(((1ull << 32) + job->tile_rows - 1) / job->tile_rows)
                             : 0u;
     t.geo.total_items = tiles_x * tiles_y * sb * 64u;
-    RT_HIP(hipMemsetAsync(ws.queue, 0, sizeof(unsigned int), c->stream));
-    if (record) RT_HIP(hipEventRecord(pairs[used].first, c->stream));
+    {
+      const uint64_t tail = (uint64_t)grid.x * kBlockThreads * kTailPathsPerLane;
+      t.geo.big_end = t.geo.total_items > tail ? (uint32_t)((t.geo.total_items - tail) / kChunkItems) * kChunkItems : 0u;
+    }
+    // which radiance buffer, and on which stream the trace runs
+    const bool piped = piped_render;
+    const int buf = piped ? (int)(c->batches_launched & 1u) : 0;
+    hipStream_t ts = piped ? c->trace_stream[buf] : c->stream;
+    t.rad = ws.rad[buf];
+    t.queue = ws.queue + 2 * buf;
+    // (the resolve that last read this buffer must be done before the trace overwrites it)
+    if (piped && c->resolved_recorded[buf]) RT_HIP(hipStreamWaitEvent(ts, c->ev_resolved[buf], 0));
+    RT_HIP(hipMemsetAsync(t.queue, 0, 2 * sizeof(unsigned int), ts));
+    if (record) RT_HIP(hipEventRecord(pairs[used].first, ts));
     if (job->kernel == RT_KERNEL_WAVEFRONT) {
       if ((rc = run_wavefront_batch(c, t, npix * sb, batched, lds))) return rc;
     } else {
       void *kernel_args[] = {&t};
-      RT_HIP(hipLaunchKernel(kernel_fn, grid, block, kernel_args, lds, c->stream));
+      RT_HIP(hipLaunchKernel(kernel_fn, grid, block, kernel_args, lds, ts));
     }
     if (record) {
-      RT_HIP(hipEventRecord(pairs[used].second, c->stream));
+      RT_HIP(hipEventRecord(pairs[used].second, ts));
       ++used;
     }
+    if (piped) {
+      RT_HIP(hipEventRecord(c->ev_traced[buf], ts));
+      RT_HIP(hipStreamWaitEvent(c->stream, c->ev_traced[buf], 0));
+    }
     ResolveArgs r;
-    r.rad = ws.rad;
+    r.rad = ws.rad[buf];
     r.acc = ws.acc;
     r.fh_acc = ws.fh_acc;
     r.npix = npix;
@@ -1869,8 +1966,16 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Work
     r.linear = linear;
     r.first_hit = first_hit;
     r.hit_sum = hit_sum;
-    hipLaunchKernelGGL(resolve_kernel, dim3((npix + 255u) / 256u), dim3(256), 0, c->stream, r);
+    // (beside a trace kernel the resolve runs as a few resident workgroups that walk the pixels, so that it
+    // trickles through HBM instead of contending for every compute unit at once)
+    const uint32_t resolve_blocks = (npix + 255u) / 256u;
+    hipLaunchKernelGGL(resolve_kernel, dim3(piped && resolve_blocks > 512u ? 512u : resolve_blocks), dim3(256), 0, c->stream, r);
     RT_HIP(hipGetLastError());
+    if (own_buffers) {
+      RT_HIP(hipEventRecord(c->ev_resolved[buf], c->stream));
+      c->resolved_recorded[buf] = true;
+    }
+    if (piped) c->batches_launched++;
   }
   if (record) {
     RT_HIP(hipEventRecord(c->ev_end, c->stream));
@@ -1946,6 +2051,13 @@ int rt_ctx_create(int device, rt_ctx **out) {
   if (!c) return fail(RT_ERR_NOMEM, "out of host memory");
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->trace_stream[0], hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->trace_stream[1], hipStreamNonBlocking);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipEventCreateWithFlags(&c->ev_traced[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_resolved[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_handover, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
   if (e != hipSuccess) {
@@ -1964,16 +2076,20 @@ int rt_ctx_create(int device, rt_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->num_cus = prop.multiProcessorCount;
-  int rc = c->counters.reserve(kNumCounters);
-  if (rc == RT_OK) rc = c->queue.reserve(1);
+  int rc = c->counters.reserve(kWaveLogBase + kWaveLogEntries);
+  if (rc == RT_OK) rc = c->queue.reserve(4);
   if (rc != RT_OK) {
     rt_ctx_destroy(c);
     return rc;
   }
-  e = hipMemsetAsync(c->counters.p, 0, kNumCounters * sizeof(unsigned long long), c->stream);
+  {
+    unsigned long long zero[kNumCounters] = {};
+    zero[14] = zero[16] = ~0ull;   // (the two minima)
+    e = hipMemcpy(c->counters.p, zero, sizeof zero, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     rt_ctx_destroy(c);
-    return fail(RT_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    return fail(RT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
   }
   *out = c;
   return RT_OK;
@@ -1983,6 +2099,8 @@ int rt_ctx_destroy(rt_ctx *c) {
   if (!c) return RT_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < 2; ++i)
+    if (c->trace_stream[i]) (void)hipStreamSynchronize(c->trace_stream[i]);
   c->filter.release();
   c->boxes.release();
   c->sboxes.release();
@@ -1995,7 +2113,8 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->type_o.release();
   c->counters.release();
   c->queue.release();
-  c->rad.release();
+  c->rad[0].release();
+  c->rad[1].release();
   c->acc.release();
   c->fh_acc.release();
   c->wf_org.release();
@@ -2015,6 +2134,13 @@ int rt_ctx_destroy(rt_ctx *c) {
     }
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+  for (int i = 0; i < 2; ++i) {
+    if (c->ev_traced[i]) (void)hipEventDestroy(c->ev_traced[i]);
+    if (c->ev_resolved[i]) (void)hipEventDestroy(c->ev_resolved[i]);
+  }
+  if (c->ev_handover) (void)hipEventDestroy(c->ev_handover);
+  for (int i = 0; i < 2; ++i)
+    if (c->trace_stream[i]) (void)hipStreamDestroy(c->trace_stream[i]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return RT_OK;
@@ -2160,11 +2286,15 @@ int rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t
   const uint32_t npix = rows * job->nx;
   Workspace ws;
   ws.batch = batch_size(npix, job->nsamples);
-  if ((rc = c->rad.reserve((size_t)ws.batch * npix))) return rc;
+  ws.pipelined = job->kernel == RT_KERNEL_MEGA && (job->flags & RT_FLAG_SERIAL) == 0;
+  if (ws.pipelined && (c->rad[0].cap < (size_t)ws.batch * npix || c->rad[1].cap < (size_t)ws.batch * npix))
+    RT_HIP(hipStreamSynchronize(c->stream));   // (a buffer about to be replaced may still be in use)
+  if ((rc = c->rad[0].reserve((size_t)ws.batch * npix)) || (ws.pipelined && (rc = c->rad[1].reserve((size_t)ws.batch * npix)))) return rc;
   // (reserve keeps what a buffer holds unless it has to grow, and the sums of a progressive render were
   // reserved for the same npix)
   if ((ws.batch < job->nsamples || progressive) && ((rc = c->acc.reserve(npix)) || (rc = c->fh_acc.reserve(npix)))) return rc;
-  ws.rad = c->rad.p;
+  ws.rad[0] = c->rad[0].p;
+  ws.rad[1] = c->rad[1].p;
   ws.acc = c->acc.p;
   ws.fh_acc = c->fh_acc.p;
   ws.queue = c->queue.p;
@@ -2213,7 +2343,9 @@ int rt_render_device_static(rt_ctx *c, const rt_camera *cam, const rt_job *job, 
   ws.counters = reinterpret_cast<unsigned long long *>(base + 64);
   ws.acc = reinterpret_cast<float4 *>(base + acc_off);
   ws.fh_acc = reinterpret_cast<int32_t *>(base + fh_off);
-  ws.rad = reinterpret_cast<float4 *>(base + rad_off);
+  ws.rad[0] = reinterpret_cast<float4 *>(base + rad_off);
+  ws.rad[1] = nullptr;
+  ws.pipelined = false;                  // (one scratch array: nothing to alternate with)
   // the array keeps the last call's contents: the queue head is cleared before every launch
   // (launch_render), the counts here; sums and radiance are written before they are read
   RT_HIP(hipMemsetAsync(base, 0, kHeader, c->stream));
@@ -2298,8 +2430,16 @@ int rt_ctx_counters(rt_ctx *c, rt_counters *out, int reset) {
     out->realtime_total = v[10];
     out->own_groups = v[11];
     out->wave_groups = v[12];
+    out->first_wave_start = v[14] == ~0ull ? 0 : v[14];
+    out->last_wave_start = v[15];
+    out->first_wave_end = v[16] == ~0ull ? 0 : v[16];
+    out->last_wave_end = v[17];
   }
-  if (reset) RT_HIP(hipMemset(c->counters.p, 0, kNumCounters * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long zero[kNumCounters] = {};
+    zero[14] = zero[16] = ~0ull;   // (the two minima)
+    RT_HIP(hipMemcpy(c->counters.p, zero, sizeof zero, hipMemcpyHostToDevice));
+  }
   return RT_OK;
 }
 
@@ -2412,6 +2552,15 @@ int rt_debug_box_pass(rt_ctx *c, const float *rays, size_t n_rays, const float *
   RT_HIP(hipMemcpy(pass_vec, d_vec, n_rays * n_boxes, hipMemcpyDeviceToHost));
   RT_HIP(hipMemcpy(pass_sca, d_sca, n_rays * n_boxes, hipMemcpyDeviceToHost));
   RT_HIP(hipMemcpy(box_ray, d_box_ray, 9 * n_rays * sizeof(float), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_debug_wave_log(rt_ctx *c, uint64_t *out, size_t n) {
+  if (!c || !out) return fail(RT_ERR_ARG, "null argument");
+  if (n > (size_t)kWaveLogEntries) n = kWaveLogEntries;
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipStreamSynchronize(c->stream));
+  RT_HIP(hipMemcpy(out, c->counters.p + kWaveLogBase, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RT_OK;
 }
 

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(rt):
 
 def test_struct_layouts(rt):
     assert C.sizeof(rt._native.RtCamera) == 88 and rt.SPHERE_DTYPE.itemsize == 36
-    assert C.sizeof(rt._native.RtJob) == 52 and C.sizeof(rt._native.RtCounters) == 112
+    assert C.sizeof(rt._native.RtJob) == 52 and C.sizeof(rt._native.RtCounters) == 144
     assert rt._native.STATIC_MAX_PIXELS * 36 + 512 <= rt._native.STATIC_SCRATCH_BYTES
 
 
