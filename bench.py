@@ -217,7 +217,7 @@ def self_launch(args):
     spec = importlib.util.spec_from_file_location("rt_launch", os.path.join(ROOT, "raytrace_amd", "launch.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    return mod.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env_extra={"RT_BENCH_SELF_LAUNCHED": "1"})
 
 
 def timed_steps(r, torch, dist, world, rehearsal, dev, step, steps):
@@ -237,9 +237,13 @@ def timed_steps(r, torch, dist, world, rehearsal, dev, step, steps):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     covered = min(steps, TRACE_HISTORY)
-    kernel_ms = [r.trace_ms(back) for back in range(covered)]          # trace kernel alone, the library's HIP events
-    launch_ms = [a.elapsed_time(b) for a, b in events]                   # trace + resolve, torch events on the same stream
-    return dt, kernel_ms, launch_ms
+    # the trace kernel bracketed by the library's HIP events on the stream it runs on.  Renders are pipelined (the
+    # next launch is dispatched while this one runs and then waits for compute units), so outside a serial leg
+    # this is dispatch-to-completion, about two steps long, and not the kernel's own duration
+    kernel_ms = [r.trace_ms(back) for back in range(covered)]
+    # a step's completion on this rank's stream to the next step's: the marginal time per render in the pipeline
+    spacing_ms = [events[k][1].elapsed_time(events[k + 1][1]) for k in range(steps - 1)]
+    return dt, kernel_ms, spacing_ms
 
 
 def main():
@@ -332,16 +336,28 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     r.counters(reset=True)
-    dt, kernel_ms, launch_ms = timed_steps(r, torch, dist, world, rehearsal, dev, step, args.steps)
+    dt, bracketed_ms, spacing_ms = timed_steps(r, torch, dist, world, rehearsal, dev, step, args.steps)
     counters = r.counters()
     paths_per_step_rank = my_rows * nx * spp_total
     total_paths_per_step = nx * ny * spp_total
+    step_ms_rank = float(np.mean(spacing_ms)) if spacing_ms else dt / args.steps * 1e3
+
+    # The kernel alone: the same frame with RT_FLAG_SERIAL (every kernel on one stream, nothing overlapped), so
+    # that the events around the trace kernel measure its duration.  This is the duration the roofline uses; the
+    # counters of this leg give the tests per launch.
+    serial_steps = min(args.steps, 10)
+    sstep, _ = make_leg(nx, ny, spp_total, flags | rt.FLAG_SERIAL)
+    sstep()
+    torch.cuda.synchronize(dev)
+    r.counters(reset=True)
+    sdt, kernel_ms, _ = timed_steps(r, torch, dist, world, rehearsal, dev, sstep, serial_steps)
+    serial_counters = r.counters()
     k_ms = float(np.mean(kernel_ms))
 
     # per-rank view: every rank's mean trace-kernel time per step and its share of the rows
     per_rank = None
     if world > 1:
-        mine = torch.tensor([k_ms, float(my_rows), float(np.mean(launch_ms))], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        mine = torch.tensor([k_ms, float(my_rows), step_ms_rank], dtype=torch.float64, device="cpu" if rehearsal else dev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         per_rank = [[float(x) for x in v.cpu()] for v in allv]
@@ -360,7 +376,7 @@ def main():
     # not part of `value`, reported beside it because it is the mode the FP32 roofline argument is about
     linear = None
     if world == 1 and rank == 0 and args.kernel == "mega" and not args.full_scan and not args.no_linear_scan_leg:
-        lstep, _ = make_leg(nx, ny, spp_total, rt.FLAG_FULL_SCAN)
+        lstep, _ = make_leg(nx, ny, spp_total, rt.FLAG_FULL_SCAN | rt.FLAG_SERIAL)
         lstep()
         torch.cuda.synchronize(dev)
         r.counters(reset=True)
@@ -375,24 +391,30 @@ def main():
                                "kernel_ms_avg": l_ms, "sphere_tests_per_path": lc["sphere_tests"] / max(1, lc["paths"])}}
 
     if rank == 0:
-        sphere_per_launch = counters["sphere_tests"] / args.steps
-        box_per_launch = counters["box_tests"] / args.steps
+        sphere_per_launch = serial_counters["sphere_tests"] / serial_steps
+        box_per_launch = serial_counters["box_tests"] / serial_steps
         achieved = FLOP_PER_TEST * sphere_per_launch / (k_ms * 1e-3) / 1e12
         with_boxes = (FLOP_PER_TEST * sphere_per_launch + FLOP_PER_BOX_TEST * box_per_launch) / (k_ms * 1e-3) / 1e12
         roof = {"bound": "fp32_valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
-                "definition": "17 FLOP x ray-sphere tests the kernel executed (device counter, this run) / mean trace-kernel time",
+                "definition": "17 FLOP x ray-sphere tests the kernel executed (device counter) / mean duration of the trace kernel, both "
+                              "from a leg of this run that renders the same frame with RT_FLAG_SERIAL (kernels one after the other on one "
+                              "stream; HIP events around the kernel on that stream).  The timed steps behind `value` are pipelined: there a "
+                              "launch's events span dispatch to completion (kernel_ms_bracketed_in_pipeline), including its wait for "
+                              "compute units behind the launch before it",
                 "kernel": "trace_kernel" if args.kernel == "mega" else "wavefront stages",
-                "kernel_ms_avg": k_ms, "kernel_ms_steps_averaged": len(kernel_ms), "render_ms_avg": float(np.mean(launch_ms)),
+                "kernel_ms_avg": k_ms, "kernel_ms_steps_averaged": len(kernel_ms), "serial_leg_ms_per_step": sdt / serial_steps * 1e3,
+                "kernel_ms_bracketed_in_pipeline": float(np.mean(bracketed_ms)), "pipelined_step_ms_rank0": step_ms_rank,
                 "flop_per_test": FLOP_PER_TEST,
                 "sphere_tests_per_launch": sphere_per_launch, "box_tests_per_launch": box_per_launch,
-                "sphere_tests_per_path": counters["sphere_tests"] / max(1, counters["paths"]),
-                "box_tests_per_path": counters["box_tests"] / max(1, counters["paths"]),
+                "sphere_tests_per_path": serial_counters["sphere_tests"] / max(1, serial_counters["paths"]),
+                "box_tests_per_path": serial_counters["box_tests"] / max(1, serial_counters["paths"]),
+                "paths_counted_in_timed_steps": counters["paths"],
                 "frac_with_box_tests": with_boxes / FP32_PEAK_TFLOPS, "flop_per_box_test": FLOP_PER_BOX_TEST,
-                "segments_per_path": counters["segments"] / max(1, counters["paths"]),
-                "exact_evaluations_per_segment": counters["candidates"] / max(1, counters["segments"]),
-                "wave_trips_per_launch": counters["wave_iterations"] / args.steps,
-                "lane_occupancy": counters["segments"] / max(1, 64 * counters["wave_iterations"]),
+                "segments_per_path": serial_counters["segments"] / max(1, serial_counters["paths"]),
+                "exact_evaluations_per_segment": serial_counters["candidates"] / max(1, serial_counters["segments"]),
+                "wave_trips_per_launch": serial_counters["wave_iterations"] / serial_steps,
+                "lane_occupancy": serial_counters["segments"] / max(1, 64 * serial_counters["wave_iterations"]),
                 "rank0_paths_per_launch": paths_per_step_rank}
         out = {
             "metric": "camera paths/sec (Msamples/s) final scene 1920x1080; % FP32 VALU peak",
@@ -413,13 +435,16 @@ def main():
                                    f"{tile_rows}-row tiles round-robin over {world} GPU(s), gather to rank 0",
                        "kernel": args.kernel, "scan": "full" if args.full_scan else "group-culled", "paths_per_step": total_paths_per_step,
                        "msamples_per_s": total_paths_per_step * args.steps / dt / 1e6,
-                       "ranks_started_by": "a launcher (WORLD_SIZE was set)" if launched else "bench.py itself"},
+                       "ranks_started_by": "bench.py itself" if (not launched or os.environ.get("RT_BENCH_SELF_LAUNCHED") == "1")
+                                           else "a launcher (WORLD_SIZE was set)"},
             "roofline": roof,
         }
         if per_rank is not None:
             ks = [v[0] for v in per_rank]
-            out["per_rank"] = {"kernel_ms": ks, "rows": [int(v[1]) for v in per_rank], "render_ms": [v[2] for v in per_rank],
-                               "kernel_ms_max_over_mean": max(ks) / (sum(ks) / len(ks))}
+            st = [v[2] for v in per_rank]
+            out["per_rank"] = {"kernel_ms_serial_leg": ks, "rows": [int(v[1]) for v in per_rank], "pipelined_step_ms": st,
+                               "kernel_ms_max_over_mean": max(ks) / (sum(ks) / len(ks)),
+                               "pipelined_step_ms_max_over_mean": max(st) / (sum(st) / len(st))}
         if weak is not None:
             out["weak_scaling"] = weak
         if linear is not None:
@@ -440,7 +465,7 @@ def main():
                     roof["algorithmic_bytes_per_launch"] = 3 * nx * ny + 16 * len(sc)
                 if pmc.get("SQ_INSTS_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
                     valu = pmc["SQ_INSTS_VALU"]
-                    trips = counters["wave_iterations"] / args.steps
+                    trips = serial_counters["wave_iterations"] / serial_steps
                     # a wave64 vector instruction occupies its SIMD's issue port for 4 cycles
                     roof["issue"] = {"valu_wave_instructions_per_launch": valu,
                                      "valu_wave_instructions_per_trip": valu / max(1.0, trips),

@@ -407,6 +407,24 @@ RT_HD bool box_pass(const BoxRay &r, const GroupBox &b) {
 // (c/main.c:220, 231 divide by the same `a` for every sphere a ray meets).
 // Infinite or NaN operands give NaN where the division gives an infinity; the
 // range test that follows fails for both.
+// (The argument above needs r only to within a few ulp: with r = (1 + eps) / da the residual e0 is still exact
+// -- it is below 2^-50 |x| and a multiple of ulp(q0) ulp(da) -- and the corrected sum is within |eps| 2^-51 of
+// the quotient, far inside the 2^-78 gap.)
+//
+// The reciprocal itself, for a positive finite float widened to double: the hardware estimate and two
+// Newton steps (within an ulp of 1 / da) instead of a full division.
+RT_HD double reciprocal_of_widened_float(double da) {
+#ifdef __HIP_DEVICE_COMPILE__
+  double r = __builtin_amdgcn_rcp(da);
+  double e = __builtin_fma(-da, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-da, r, 1.0);
+  return __builtin_fma(r, e, r);
+#else
+  return 1.0 / da;
+#endif
+}
+
 RT_HD double div_by_widened_float(double x, double da, double r) {
   double q0 = x * r;
   double e0 = __builtin_fma(-q0, da, x);

@@ -104,6 +104,8 @@ struct DeviceScene {
   const float4 *mat_o;    // {albedo rgb, param}
   const int32_t *type_o;  // material type
   const double *inv_r_o;  // 1.0 / (double)radius, for the divisions of c/main.c:229 (div_f32_by)
+  const float4 *shade_o;  // the same four per sphere as one 48-byte record: {cx, cy, cz, radius}, {albedo rgb, param},
+                          // {1.0 / (double)radius as two words, type, 0} -- what the megakernel's shading reads
   const uint8_t *group_real;   // n_pad/8 entries: real (non-pad) spheres per group
   uint32_t n, n_pad;
   float sigma0, sigma1;   // per-ray growth of the group boxes (rt_core.h, rt_cluster.h)
@@ -773,7 +775,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   w.tmin = tmin;
   // this lane's ray and "no hit yet" key where the other lanes of the wave can reach them; the
   // key {tmax bits, 0} can only be undercut by t < tmax
-  const double inv_a = 1.0 / (double)a;   // one division per ray, none per sphere
+  const double inv_a = reciprocal_of_widened_float((double)a);   // one reciprocal per ray, no division per sphere
   lds.rays[3 * tid] = make_float4(A.x, A.y, A.z, a);
   lds.rays[3 * tid + 1] = make_float4(B.x, B.y, B.z, f.na);
   lds.rays[3 * tid + 2] = make_float4(__int_as_float(__double2loint(inv_a)), __int_as_float(__double2hiint(inv_a)), f.ab, f.naaa);
@@ -896,14 +898,6 @@ struct PathGeom {
   double inv_nx, inv_ny;  // 1.0 / (double)(float)nx, ny (pixel_xy_by)
 };
 
-// the tables shading reads, in the caller's sphere order (a contiguous part of DeviceScene)
-struct ShadeTables {
-  const float4 *geom_o;
-  const float4 *mat_o;
-  const int32_t *type_o;
-  const double *inv_r_o;
-};
-static_assert(offsetof(DeviceScene, inv_r_o) - offsetof(DeviceScene, geom_o) == offsetof(ShadeTables, inv_r_o), "same layout");
 
 struct TraceArgs {
   Camera cam;
@@ -1024,12 +1018,13 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
         bool done = false;
         if (depth == 0) first_hit = h.index;
         if (h.index >= 0) {
-          const ShadeTables tab = kernarg_now<ShadeTables>(offsetof(TraceArgs, sc) + offsetof(DeviceScene, geom_o));
-          const float4 e = tab.geom_o[h.index];
-          const float4 m4 = tab.mat_o[h.index];
-          const int type = tab.type_o[h.index];
+          const float4 *rec = kernarg_now<const float4 *>(offsetof(TraceArgs, sc) + offsetof(DeviceScene, shade_o)) + 3 * h.index;
+          const float4 e = rec[0];
+          const float4 m4 = rec[1];
+          const float4 tail = rec[2];
+          const int type = __float_as_int(tail.z);
           p = A + h.closest * B;                              // c/structs.c:6-8
-          const double inv_r = tab.inv_r_o[h.index];
+          const double inv_r = __hiloint2double(__float_as_int(tail.y), __float_as_int(tail.x));
           const V3 pc = p - v3(e.x, e.y, e.z);
           n = v3(div_f32_by(pc.x, e.w, inv_r), div_f32_by(pc.y, e.w, inv_r), div_f32_by(pc.z, e.w, inv_r));   // c/main.c:229
           if (type == RT_DIELECTRIC) {
@@ -1609,7 +1604,7 @@ __global__ void debug_arith_kernel(int op, const double *a, const double *b, uin
     case RT_ARITH_SQRT_WIDENED: r = sqrt_of_widened_positive_float((double)(float)x); break;
     case RT_ARITH_DIV_WIDENED: {
       const double da = (double)(float)y;
-      r = div_by_widened_float(x, da, 1.0 / da);
+      r = div_by_widened_float(x, da, reciprocal_of_widened_float(da));
     } break;
     case RT_ARITH_DIV_F32_BY: r = (double)div_f32_by((float)x, (float)y, 1.0 / (double)(float)y); break;
     case RT_ARITH_RCP_NARROWED: r = (double)narrowed_double_reciprocal((float)x); break;
@@ -1718,7 +1713,7 @@ struct rt_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events[kHistory];
   int trace_used[kHistory] = {};
   long renders = 0;
-  DevBuf<float4> filter, boxes, sboxes, exact, geom_o, mat_o;
+  DevBuf<float4> filter, boxes, sboxes, exact, geom_o, mat_o, shade_o;
   DevBuf<int32_t> type_o;
   DevBuf<uint32_t> orig;
   DevBuf<double> inv_r_o;
@@ -1761,7 +1756,7 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full, c->n_always_groups};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->shade_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full, c->n_always_groups};
 }
 
 size_t scan_lds_bytes(uint32_t entries, bool cull) {
@@ -2106,6 +2101,7 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->sboxes.release();
   c->orig.release();
   c->inv_r_o.release();
+  c->shade_o.release();
   c->group_real.release();
   c->exact.release();
   c->geom_o.release();
@@ -2183,6 +2179,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   std::vector<float4> filter(n_pad), exact(n_pad), boxes(3 * (n_pad / 16)), sboxes(3 * (n_pad / 64)), geom_o(n), mat_o(n);
   std::vector<int32_t> type_o(n);
   std::vector<double> inv_r_o(n);
+  std::vector<float4> shade_o(3 * n);
   std::vector<FilterSphere> fs(n_pad);
   for (size_t i = 0; i < n; ++i) {
     const rt_sphere &s = spheres[i];
@@ -2190,6 +2187,15 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     mat_o[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
     type_o[i] = s.type;
     inv_r_o[i] = 1.0 / (double)s.radius;
+    uint32_t w[2];
+    std::memcpy(w, &inv_r_o[i], sizeof w);
+    float lo, hi, ty;
+    std::memcpy(&lo, &w[0], 4);
+    std::memcpy(&hi, &w[1], 4);
+    std::memcpy(&ty, &s.type, 4);
+    shade_o[3 * i] = geom_o[i];
+    shade_o[3 * i + 1] = mat_o[i];
+    shade_o[3 * i + 2] = make_float4(lo, hi, ty, 0.0f);
   }
   for (uint32_t p = 0; p < n_pad; ++p) {
     const uint32_t i = L.order[p];
@@ -2234,7 +2240,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   int rc;
   if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(sboxes.size())) || (rc = c->exact.reserve(n_pad)) ||
       (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
-      (rc = c->orig.reserve(n_pad)) || (rc = c->inv_r_o.reserve(n)) || (rc = c->group_real.reserve(n_pad / 8)))
+      (rc = c->orig.reserve(n_pad)) || (rc = c->inv_r_o.reserve(n)) || (rc = c->shade_o.reserve(3 * n)) || (rc = c->group_real.reserve(n_pad / 8)))
     return rc;
   RT_HIP(hipStreamSynchronize(c->stream));
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
@@ -2245,6 +2251,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->type_o.p, type_o.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->inv_r_o.p, inv_r_o.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->shade_o.p, shade_o.data(), 3 * n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->group_real.p, L.real_in_group.data(), n_pad / 8, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->orig.p, L.order.data(), n_pad * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->scene_generation++;
