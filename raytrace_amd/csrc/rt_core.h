@@ -487,9 +487,22 @@ RT_HD bool exact_hit(V3 A, V3 B, float a, double inv_a, float cx, float cy, floa
 // c/main.c:140-144.  (1-cosine)^5 by three double products instead of libm
 // pow: agrees with it to a few units of the last double place, which the
 // narrowing to float hides except about once in 2^27 calls.
-RT_HD float schlick(float cosine, float ref_idx) {
+// The two lines of c/main.c:141-142 depend on the sphere alone: r0 = ((1 - n) / (1 + n))^2 in float
+// arithmetic.  schlick_r0 computes them (on the host at scene upload, or here), schlick_with the rest.
+RT_HD float schlick_r0(float ref_idx) {
   float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
-  r0 = r0 * r0;
+  return r0 * r0;
+}
+
+RT_HD float schlick_with(float cosine, float r0) {
+  double x = (double)(1.0f - cosine);
+  double x2 = x * x;
+  double x5 = x2 * x2 * x;
+  return (float)((double)r0 + (double)(1.0f - r0) * x5);
+}
+
+RT_HD float schlick(float cosine, float ref_idx) {
+  float r0 = schlick_r0(ref_idx);
   double x = (double)(1.0f - cosine);
   double x2 = x * x;
   double x5 = x2 * x2 * x;
@@ -540,7 +553,9 @@ RT_HD bool scatter_metal_unit(V3 unitB, V3 n, float fuzz, V3 ball, V3 &dir) {
 RT_HD bool scatter_metal(V3 B, V3 n, float fuzz, V3 ball, V3 &dir) { return scatter_metal_unit(normalize(B), n, fuzz, ball, dir); }
 
 // dielectric, c/main.c:181-206: the new direction
-RT_HD V3 scatter_dielectric_unit(V3 B, V3 unitB, float lenB, V3 n, float idx, Rng &g) {
+// r0 = schlick_r0(idx) and inv_idx = narrowed_double_reciprocal(idx), (float)(1.0 / (double)idx) of c/main.c:193,
+// are per-sphere constants that a caller may have at hand
+RT_HD V3 scatter_dielectric_unit(V3 B, V3 unitB, float lenB, V3 n, float idx, float r0, float inv_idx, Rng &g) {
   float bn = dot(B, n);
   V3 outward;
   float ni_over_nt, cosine;
@@ -550,19 +565,19 @@ RT_HD V3 scatter_dielectric_unit(V3 B, V3 unitB, float lenB, V3 n, float idx, Rn
     cosine = idx * bn / lenB;
   } else {
     outward = n;
-    ni_over_nt = narrowed_double_reciprocal(idx);   // (float)(1.0 / (double)idx), c/main.c:193
+    ni_over_nt = inv_idx;
     cosine = -bn / lenB;
   }
   V3 bent;
   bool go_through = false;
   if (refract_unit(unitB, outward, ni_over_nt, bent)) {
-    go_through = next_uniform(g) >= (double)schlick(cosine, idx);
+    go_through = next_uniform(g) >= (double)schlick_with(cosine, r0);
   }
   return go_through ? bent : reflect(B, n);
 }
 
 RT_HD V3 scatter_dielectric(V3 B, V3 n, float idx, Rng &g) {
-  return scatter_dielectric_unit(B, normalize(B), length(B), n, idx, g);
+  return scatter_dielectric_unit(B, normalize(B), length(B), n, idx, schlick_r0(idx), narrowed_double_reciprocal(idx), g);
 }
 
 // c/main.c:163-211.  p, n: hit point and normal.  Returns false for an

@@ -104,7 +104,8 @@ struct DeviceScene {
   const float4 *mat_o;    // {albedo rgb, param}
   const int32_t *type_o;  // material type
   const double *inv_r_o;  // 1.0 / (double)radius, for the divisions of c/main.c:229 (div_f32_by)
-  const float4 *shade_o;  // the same four per sphere as one 48-byte record: {cx, cy, cz, radius}, {albedo rgb, param},
+  const float4 *shade_o;  // the same four per sphere as one 48-byte record: {cx, cy, cz, radius}, {albedo rgb, param}
+                          // (a dielectric: {r0 of its Schlick term, 1 / ref_idx, 0, ref_idx}),
                           // {1.0 / (double)radius as two words, type, 0} -- what the megakernel's shading reads
   const uint8_t *group_real;   // n_pad/8 entries: real (non-pad) spheres per group
   uint32_t n, n_pad;
@@ -1028,7 +1029,8 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
           const V3 pc = p - v3(e.x, e.y, e.z);
           n = v3(div_f32_by(pc.x, e.w, inv_r), div_f32_by(pc.y, e.w, inv_r), div_f32_by(pc.z, e.w, inv_r));   // c/main.c:229
           if (type == RT_DIELECTRIC) {
-            B = scatter_dielectric_unit(B, unitB, lenB, n, m4.w, g);   // attenuation 1 (c/main.c:183)
+            // (a dielectric has no albedo -- attenuation 1, c/main.c:183 -- and its record carries r0 and 1 / idx there)
+            B = scatter_dielectric_unit(B, unitB, lenB, n, m4.w, m4.x, m4.y, g);
             A = p;
             depth++;
             done = depth >= job.max_depth;                    // c/main.c:262, 282
@@ -2194,7 +2196,9 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     std::memcpy(&hi, &w[1], 4);
     std::memcpy(&ty, &s.type, 4);
     shade_o[3 * i] = geom_o[i];
-    shade_o[3 * i + 1] = mat_o[i];
+    shade_o[3 * i + 1] = s.type == RT_DIELECTRIC
+                             ? make_float4(schlick_r0(s.param), narrowed_double_reciprocal(s.param), 0.0f, s.param)   // c/main.c:141-142, 193
+                             : mat_o[i];
     shade_o[3 * i + 2] = make_float4(lo, hi, ty, 0.0f);
   }
   for (uint32_t p = 0; p < n_pad; ++p) {
