@@ -135,6 +135,9 @@ PMC_PASSES = [
 ]
 
 
+PMC_CHILD_RENDERS = 2
+
+
 def pmc_child(args):
     """Run under rocprofv3 by live_pmc(): two renders of the workload through the host-pointer entry, nothing else."""
     import raytrace_amd as rt
@@ -145,14 +148,15 @@ def pmc_child(args):
     r.upload(sc)
     cam = rt.camera_default(nx, ny)
     job = rt.Job(nx, ny, spp, max_depth=max_depth, seed=0, flags=rt.FLAG_FULL_SCAN if args.full_scan else 0)
-    for _ in range(2):
+    for _ in range(PMC_CHILD_RENDERS):
         r.render_host(cam, job, debug=False)
     r.close()
 
 
 def live_pmc(args, workload):
     """rocprofv3 --pmc around a child of this script, one pass per counter block (FETCH_SIZE and WRITE_SIZE do not
-    fit one pass), each under a hard time limit.  Returns per-launch averages for the trace kernel, or an error."""
+    fit one pass), each under a hard time limit.  Returns the trace kernel's counters per RENDER of the workload
+    (summed over the launches of a render: a frame whose radiance does not fit one buffer takes several), or an error."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
@@ -184,8 +188,9 @@ def live_pmc(args, workload):
             if not calls:
                 return {"error": f"pass {name}: no trace_kernel rows in the counter output"}
             for c, v in sums.items():
-                out[c] = v / len(calls)
+                out[c] = v / PMC_CHILD_RENDERS
             out.setdefault("launches_profiled", {})[name] = len(calls)
+            out["launches_per_render"] = len(calls) / PMC_CHILD_RENDERS
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"[:300]}
     finally:
@@ -460,20 +465,20 @@ def main():
             if "error" not in pmc:
                 roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, run by this bench.py in this run"
                 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                    # KB per launch; a 128-byte read request is tallied as 64 bytes on gfx950, 16-byte stores exactly
+                    # KB per render; a 128-byte read request is tallied as 64 bytes on gfx950, 16-byte stores exactly
                     roof["traffic"] = (pmc["WRITE_SIZE"] + 2.0 * pmc["FETCH_SIZE"]) * 1024.0
                     roof["algorithmic_bytes_per_launch"] = 3 * nx * ny + 16 * len(sc)
                 if pmc.get("SQ_INSTS_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
                     valu = pmc["SQ_INSTS_VALU"]
                     trips = serial_counters["wave_iterations"] / serial_steps
                     # a wave64 vector instruction occupies its SIMD's issue port for 4 cycles
-                    roof["issue"] = {"valu_wave_instructions_per_launch": valu,
+                    roof["issue"] = {"valu_wave_instructions_per_render": valu,
                                      "valu_wave_instructions_per_trip": valu / max(1.0, trips),
                                      "frac_of_issue_slots": valu * 4.0 / (SIMDS / 8 * pmc["GRBM_GUI_ACTIVE"]),
                                      "thread_efficiency": (pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
                                                            if pmc.get("SQ_ACTIVE_INST_VALU") else None),
                                      "salu_per_valu": pmc.get("SQ_INSTS_SALU", 0.0) / valu,
-                                     "gpu_cycles_per_launch_under_profiler": pmc["GRBM_GUI_ACTIVE"] / 8.0,
+                                     "gpu_cycles_per_render_under_profiler": pmc["GRBM_GUI_ACTIVE"] / 8.0,
                                      "clock_ghz_if_those_cycles_took_the_timed_kernel_ms": pmc["GRBM_GUI_ACTIVE"] / 8.0 / (k_ms * 1e-3) / 1e9,
                                      "definition": "VALU wave-instructions x 4 cycles / (1024 SIMDs x GPU-active cycles of the launch), both from "
                                                    "the same rocprofv3 pass (GRBM_GUI_ACTIVE is summed over the 8 XCDs)"}

@@ -789,10 +789,14 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   }
   RT_HSTAGE_END(35);
   if (kBatched) {
-    // Which batches to stage: those whose box some ray of the workgroup can touch.  Every lane tests
-    // its ray against every batch box (two per packed evaluation, the boxes read through the scalar
-    // cache one pair ahead); a wave's union goes to LDS, and after a barrier every wave holds the
-    // workgroup's union -- the same in all of them, as the barriers around the staging need.
+    // A scene too large for LDS is scanned where it lies: its pair image, boxes and group sizes are read from
+    // global memory (the 16 bytes per sphere of even a 65,535-sphere scene stay in the L2 of every XCD), batch
+    // by batch -- a batch is kBatchSpheres scan positions with a box of its own.  Which batches: those whose
+    // box some ray of the WAVE can touch.  Every lane tests its ray against every batch box (two per packed
+    // evaluation, the boxes read through the scalar cache one pair ahead).  Nothing is shared between the
+    // waves of the workgroup, so there is no barrier in the scan and a wave visits only what its own 64 rays
+    // need.  (Staging each batch into LDS for the whole workgroup, two barriers per batch, left the vector
+    // ALUs idle 60 % of the time.)
     unsigned long long want_lo = ~0ull, want_hi = ~0ull;   // (without culling: every batch)
     if (kCull) {
       typedef __attribute__((address_space(4))) const float *ScalarFloats;
@@ -817,19 +821,9 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       }
       if (all_mask != 0ull) mine_lo = mine_hi = ~0ull;
       h.box_tests += 2u * n_batch_pairs;
-      if (w.lane == 0u) {
-        lds.bmask[2u * (tid >> 6)] = mine_lo;
-        lds.bmask[2u * (tid >> 6) + 1u] = mine_hi;
-      }
-      __syncthreads();
-      want_lo = (lds.bmask[0] | lds.bmask[2]) | (lds.bmask[4] | lds.bmask[6]);
-      want_hi = (lds.bmask[1] | lds.bmask[3]) | (lds.bmask[5] | lds.bmask[7]);
-      want_lo = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(want_lo >> 32)) << 32) |
-                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)want_lo);
-      want_hi = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(want_hi >> 32)) << 32) |
-                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)want_hi);
+      want_lo = mine_lo;
+      want_hi = mine_hi;
     }
-    static_assert(kBlockThreads / 64 == 4, "four waves' masks are combined");
     static_assert((kMaxSpheres + kBatchSpheres) / kBatchSpheres <= 128u, "two 64-bit masks");
 #pragma unroll 1
     for (uint32_t half = 0; half < 2u; ++half) {
@@ -839,12 +833,14 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
         want &= want - 1ull;
         if (base >= sc.n_pad) break;   // (a mask with every bit set names batches that do not exist)
         const uint32_t count = min(kBatchSpheres, sc.n_pad - base);
-        __syncthreads();
-        stage_batch(sc, lds, base, count, tid);
-        __syncthreads();
         // (without culling the trailing padding is not visited)
         const uint32_t span = kCull ? count : (sc.n_full > base ? min(count, sc.n_full - base) : 0u);
-        scan_batch<kCull>(sc, lds, base, span, fr, br, alive, uncullable, w, h);
+        ScanLds in_place = lds;   // (the per-wave lists, rays and keys stay in LDS; the scene's arrays are the global ones)
+        in_place.pairs = const_cast<float4 *>(sc.filter + base);
+        in_place.boxes = const_cast<float4 *>(sc.boxes + 3u * (base / 16u));
+        in_place.sboxes = const_cast<float4 *>(sc.sboxes + 3u * (base / 64u));
+        in_place.real8 = const_cast<uint8_t *>(sc.group_real + base / 8u);
+        scan_batch<kCull>(sc, in_place, base, span, fr, br, alive, uncullable, w, h);
       }
     }
   } else {
@@ -935,11 +931,11 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 // and, with its short lists, 32,000 bytes of LDS, so five workgroups share a CU; the other variants keep
 // four, i.e. at most 128 VGPRs.)
 template <bool kBatched, bool kCull, bool kProfile>
-__global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void trace_kernel(const TraceArgs args) {
+__global__ __launch_bounds__(kBlockThreads, kCull ? 5 : 4) void trace_kernel(const TraceArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DeviceScene &sc = args.sc;
   const rt_job &job = args.geo.job;
-  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? kBatchSpheres : sc.n_pad);
+  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? 0u : sc.n_pad);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -1177,14 +1173,8 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
       c_shade += c3 - c2;
     }
     // ---- next trip, or the end: nothing to trace and nothing left to hand out
-    if (kBatched) {
-      // (the votes are the same in every lane; readfirstlane tells the compiler so)
-      work = __builtin_amdgcn_readfirstlane(__syncthreads_or(alive ? 1 : 0)) != 0;
-      if (!work && __builtin_amdgcn_readfirstlane(__syncthreads_and(exhausted ? 1 : 0))) break;
-    } else {
-      work = wave_any(alive);
-      if (!work && exhausted) break;
-    }
+    work = wave_any(alive);
+    if (!work && exhausted) break;
   }
 
   if (kProfile && lane == 0 && args.counters) {
@@ -1363,7 +1353,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t qcnt[4], qbase[4];
   const DeviceScene &sc = args.sc;
-  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? kBatchSpheres : sc.n_pad);
+  const ScanLds lds = carve_lds<kCull>(smem, kBatched ? 0u : sc.n_pad);
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid < 4) qcnt[tid] = 0;
   if (!kBatched) stage_batch(sc, lds, 0u, sc.n_pad, tid);
@@ -1378,11 +1368,7 @@ __global__ __launch_bounds__(kBlockThreads) void wf_intersect(const TraceArgs ar
     const bool alive = slot < pool.slots && pool.misc[slot].w != kWfDead;
     q[sub] = -1;
     pos[sub] = 0;
-    if (kBatched) {
-      if (!__builtin_amdgcn_readfirstlane(__syncthreads_or(alive ? 1 : 0))) continue;   // (same vote in every lane)
-    } else {
-      if (!wave_any(alive)) continue;
-    }
+    if (!wave_any(alive)) continue;
     V3 A = v3(0, 0, 0), B = v3(0, 0, 1);
     if (alive) {
       float4 o = pool.org[slot], d = pool.dir[slot];
@@ -1495,7 +1481,7 @@ template <bool kCull>
 __global__ __launch_bounds__(kBlockThreads) void closest_hit_kernel(DeviceScene sc, const float *rays, uint32_t n_rays,
                                                                      float tmin, float tmax, int32_t *index, float *t) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const ScanLds lds = carve_lds<kCull>(smem, kBatchSpheres);
+  const ScanLds lds = carve_lds<kCull>(smem, 0u);
   const uint32_t tid = threadIdx.x;
   const uint32_t r = blockIdx.x * kBlockThreads + tid;
   const bool alive = r < n_rays;
@@ -1768,7 +1754,7 @@ size_t scan_lds_bytes(uint32_t entries, bool cull) {
          (size_t)((entries / 8u + 15u) & ~15u) +                                            // real spheres per group
          (size_t)(kBlockThreads / 64) * 2 * sizeof(unsigned long long);                      // batch masks
 }
-size_t trace_lds_bytes(uint32_t n_pad, bool cull) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : kBatchSpheres, cull); }
+size_t trace_lds_bytes(uint32_t n_pad, bool cull) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : 0u, cull); }
 
 // samples per launch: the radiance buffer holds batch * pixels float4 and is
 // kept under kRadBudgetBytes
@@ -2471,7 +2457,7 @@ int rt_debug_closest_hit(rt_ctx *c, const float *rays, size_t n_rays, float tmin
   }
   hipError_t e = hipMemcpy(d_rays.p, rays, 6 * n_rays * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    size_t lds = scan_lds_bytes(kBatchSpheres, true);
+    size_t lds = scan_lds_bytes(0u, true);
     uint32_t blocks = (uint32_t)((n_rays + kBlockThreads - 1) / kBlockThreads);
     hipLaunchKernelGGL(closest_hit_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds, c->stream, scene_view(c), d_rays.p,
                        (uint32_t)n_rays, tmin, tmax, d_idx.p, d_t.p);
