@@ -213,6 +213,9 @@ def parse_args():
     ap.add_argument("--full-scan", action="store_true", help="RT_FLAG_FULL_SCAN: filter every sphere for every ray (no group culling)")
     ap.add_argument("--no-linear-scan-leg", action="store_true", help="skip the extra (untimed for `value`) full-scan measurement")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 counter passes (N = 1 only) that fill roofline.traffic and roofline.issue")
+    ap.add_argument("--serial", action="store_true", help="RT_FLAG_SERIAL for the timed steps too: no overlap between renders (the form to "
+                                                          "profile: every trace-kernel launch then shows its own duration)")
+    ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp frames (profiling runs: keeps the kernel list uniform)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -326,17 +329,22 @@ def main():
                 gather_frame(shards, tiles, rank, frame, gathered)     # the only communication: tiles -> rank 0
         return step, rt.job_rows(job)
 
-    flags = rt.FLAG_FULL_SCAN if args.full_scan else 0
+    flags = (rt.FLAG_FULL_SCAN if args.full_scan else 0) | (rt.FLAG_SERIAL if args.serial else 0)
     step, my_rows = make_leg(nx, ny, spp_total, flags)
 
     # bring the clocks up before anything is measured (the first frames after idle run 5-10 % slower);
     # these frames are neither warm-up steps nor timed steps
-    ramp_cam, ramp_job = rt.camera_default(1920, 1080), rt.Job(1920, 1080, 16, seed=0, kernel=kernel, flags=flags)
-    ramp_out = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device=dev)
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.5:
-        r.render_device(ramp_cam, ramp_job, ramp_out.data_ptr())
-        torch.cuda.synchronize(dev)
+    if nx * ny * spp_total // world > 4 * 10 ** 8:                        # a frame of seconds: ramp on a small one
+        ramp_cam, ramp_job = rt.camera_default(1920, 1080), rt.Job(1920, 1080, 16, seed=0, kernel=kernel, flags=flags)
+        ramp_out = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device=dev)
+        while not args.no_ramp and time.perf_counter() - t_ramp < 0.5:
+            r.render_device(ramp_cam, ramp_job, ramp_out.data_ptr())
+            torch.cuda.synchronize(dev)
+    else:                                                                    # the workload's own frame
+        while not args.no_ramp and time.perf_counter() - t_ramp < 0.5:
+            step()
+            torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -439,6 +447,7 @@ def main():
                                    f", max_depth {max_depth}, deterministic counter-RNG mode, "
                                    f"{tile_rows}-row tiles round-robin over {world} GPU(s), gather to rank 0",
                        "kernel": args.kernel, "scan": "full" if args.full_scan else "group-culled", "paths_per_step": total_paths_per_step,
+                       "renders": "one after the other (RT_FLAG_SERIAL)" if args.serial else "pipelined on the context",
                        "msamples_per_s": total_paths_per_step * args.steps / dt / 1e6,
                        "ranks_started_by": "bench.py itself" if (not launched or os.environ.get("RT_BENCH_SELF_LAUNCHED") == "1")
                                            else "a launcher (WORLD_SIZE was set)"},

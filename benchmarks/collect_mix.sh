@@ -5,7 +5,7 @@ tag=${1:-mix}; shift || true
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-cmd=(python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-linear-scan-leg "$@")
+cmd=(python3 bench.py --steps 3 --warmup 1 --serial --no-cpu-baseline --no-linear-scan-leg --no-live-pmc "$@")
 run() {
   local name=$1; shift
   timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$out/$name" -o "$name" -- "${cmd[@]}" >> "$out/log.txt" 2>&1

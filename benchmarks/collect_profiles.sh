@@ -8,7 +8,7 @@ tag=${1:-prof}; shift || true
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-cmd=(python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-linear-scan-leg "$@")
+cmd=(python3 bench.py --steps 3 --warmup 1 --serial --no-cpu-baseline --no-linear-scan-leg --no-live-pmc "$@")
 
 run() {  # name, then rocprofv3 options
   local name=$1; shift
@@ -25,6 +25,7 @@ run pmc_sq2 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INS
 run pmc_sq3 --pmc SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM || exit 1
 run pmc_fetch --pmc FETCH_SIZE GRBM_GUI_ACTIVE || exit 1
 run pmc_write --pmc WRITE_SIZE || exit 1
+run pmc_salu --pmc SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU || echo 'pmc_salu pass failed (counter not available?)'
 run pmc_occ --pmc OccupancyPercent || exit 1
 run pmc_valubusy --pmc VALUBusy || exit 1
 run pmc_valuutil --pmc VALUUtilization || exit 1

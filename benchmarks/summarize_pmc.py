@@ -24,16 +24,3 @@ for path in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collect
         out.setdefault(k, {}).update({c: v / n for c, v in d.items()})
         out[k]["dispatches_profiled"] = n
 print(json.dumps(out, indent=1, sort_keys=True))
-# usage with a second argument "culled" or "full": also refresh that entry of profiles/pmc_latest.json (read by bench.py)
-if len(sys.argv) > 2:
-    latest = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")
-    try:
-        cur = json.load(open(latest))
-    except Exception:
-        cur = {}
-    tk = next(v for k, v in out.items() if k.startswith("trace_kernel"))
-    cur[sys.argv[2]] = {"FETCH_SIZE_KB": tk["FETCH_SIZE"], "WRITE_SIZE_KB": tk["WRITE_SIZE"],
-                        "VALUBusy": tk.get("VALUBusy"), "VALUUtilization": tk.get("VALUUtilization"),
-                        "SQ_INSTS_VALU": tk.get("SQ_INSTS_VALU"),
-                        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py final1080, " + os.path.basename(root.rstrip("/"))}
-    json.dump(cur, open(latest, "w"), indent=1, sort_keys=True)

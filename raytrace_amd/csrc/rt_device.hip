@@ -650,12 +650,45 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
       w.pcnt += (uint32_t)__popcll(m);
     }
   };
-  // the groups every ray scans (the scene's few large spheres): on every live lane's list, untested
-  // (the lanes that list every group anyway get them from the rounds below)
-  // (at most kSuper of them, 64 entries each: the list, empty at this point, holds them)
-  static_assert(kPairListCap >= 64u * rtcluster::kSuper, "the untested groups must fit the list");
+  // The groups every ray scans (the scene's few large spheres) are filtered here, by every lane for its own
+  // ray from the coefficients it holds in registers, the spheres read as wave-wide broadcasts: no list entry,
+  // no reading back of the ray.  (The lanes that list every group anyway get them from the rounds below.)
+  // Four spheres at a time, so that what one step appends (at most 64 * 4 entries) fits the list.
+  static_assert(kWaveListCapCull >= 64u * (kChunk / 2), "half a group's candidates must fit the list");
   if (base == 0u) {
-    for (uint32_t g = 0; g < sc.n_always_groups; ++g) list_group(live_mask & ~all_mask, alive && !uncullable, g);
+    const unsigned long long own_mask = live_mask & ~all_mask;
+    const bool own = alive && !uncullable;
+    for (uint32_t g = 0; g < sc.n_always_groups; ++g) {
+      const uint32_t real = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lds.real8[g]);
+#pragma unroll 1
+      for (uint32_t half = 0; half < 2u; ++half) {
+        if (half == 1u && real <= (uint32_t)(kChunk / 2)) break;
+        if (w.wcnt + 64u * (kChunk / 2) > kWaveListCapCull) drain_wave(sc, w, h);
+        const float4 *src = lds_pairs + g * kChunk + 4u * half;
+        const float4 q[4] = {src[0], src[1], src[2], src[3]};
+        f32x2 d[2];
+        filter_two_pairs(fr, q, d[0], d[1]);
+        unsigned long long m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = __ballot(d[u >> 1][u & 1] > 0.0f) & own_mask;
+        if (((m[0] | m[1]) | (m[2] | m[3])) != 0ull) {
+          asm volatile("");
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (m[u] != 0ull) {
+              asm volatile("");
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+              uint32_t pos = g * kChunk + 4u * half + (uint32_t)u, tail = w.wlist_off + (w.wcnt << 2);
+              asm("" : "+s"(pos), "+s"(tail));   // keep each one scalar operand
+              lds_u32 *dst = (lds_u32 *)(uintptr_t)(tail + (rank << 2));
+              if (d[u >> 1][u & 1] > 0.0f && own) *dst = w.lane16 | pos;
+              w.wcnt += (uint32_t)__popcll(m[u]);
+            }
+          }
+        }
+      }
+      h.lane_tests += own ? real : 0u;
+    }
   }
   // Super-groups first, all of them in one tight loop (the boxes of a pair of super-groups, 64 spheres,
   // in one packed evaluation; two pairs per trip so that the reads of one overlap the arithmetic of the
