@@ -964,7 +964,7 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 // and, with its short lists, 32,000 bytes of LDS, so five workgroups share a CU; the other variants keep
 // four, i.e. at most 128 VGPRs.)
 template <bool kBatched, bool kCull, bool kProfile>
-__global__ __launch_bounds__(kBlockThreads, kCull ? 5 : 4) void trace_kernel(const TraceArgs args) {
+__global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void trace_kernel(const TraceArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DeviceScene &sc = args.sc;
   const rt_job &job = args.geo.job;
