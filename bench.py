@@ -95,8 +95,9 @@ def cpu_baseline(nx, ny, scene_name, half_extent, max_depth):
         sc = {"random_scene": lambda: orc.scene_random(half_extent or 11), "glass_scene": lambda: orc.scene_glass(half_extent or 11),
               "small_scene": orc.scene_small}[scene_name]()
         cam = orc.camera_default(nx, ny)
-        spp = 4 if len(sc) < 2000 else 1
-        rows = ny if len(sc) < 2000 else max(8, ny // 60)
+        # about 10 s of work per build on 16 cores (the dense field is a linear scan of 40,004 spheres per ray)
+        spp = 24 if len(sc) < 2000 else 1
+        rows = ny if len(sc) < 2000 else max(8, ny // 12)
         row0 = (ny - rows) // 2
         t0 = time.perf_counter()
         out = orc.render_det(cam, sc, nx, ny, spp, max_depth=max_depth, seed=0, row0=row0, rows=rows, host_threads=cores,
@@ -335,7 +336,9 @@ def main():
     # bring the clocks up before anything is measured (the first frames after idle run 5-10 % slower);
     # these frames are neither warm-up steps nor timed steps
     t_ramp = time.perf_counter()
-    if nx * ny * spp_total // world > 4 * 10 ** 8:                        # a frame of seconds: ramp on a small one
+    # (with several ranks the workload's step holds a collective, and ranks looping on their own clocks would call
+    # it different numbers of times: they ramp on a local frame)
+    if world > 1 or nx * ny * spp_total > 4 * 10 ** 8:                    # or a frame of seconds: ramp on a small one
         ramp_cam, ramp_job = rt.camera_default(1920, 1080), rt.Job(1920, 1080, 16, seed=0, kernel=kernel, flags=flags)
         ramp_out = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device=dev)
         while not args.no_ramp and time.perf_counter() - t_ramp < 0.5:
