@@ -107,8 +107,14 @@ def cpu_baseline(nx, ny, scene_name, half_extent, max_depth):
         results[tag] = {"value": paths / dt, "seconds": dt, "flags": flags}
         sample = (f"{nx}x{ny} rows {row0}..{row0 + rows - 1}, {spp} spp, {paths} paths; oracle/rt_oracle.c, {cores} pthreads "
                   f"over interleaved rows ({cores_note})")
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), None)
+    except OSError:
+        pass
     best = max(results, key=lambda k: results[k]["value"])
-    res = {"value": results[best]["value"], "unit": "camera paths/s", "cores": cores, "kind": "port", "sample": sample,
+    res = {"cpu_model": cpu_model, "value": results[best]["value"], "unit": "camera paths/s", "cores": cores, "kind": "port", "sample": sample,
            "build": results[best]["flags"], "builds": results}
     if native_error:
         res["native_build_error"] = native_error

@@ -8,6 +8,8 @@ product is the native code under csrc/ and host/.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _native as N
@@ -75,6 +77,28 @@ def glass_scene(half_extent=11):
     g = _fresh_rng()
     got = N.host.rth_scene_glass(s.ctypes.data, n, half_extent, C.byref(g))
     return s[:got].copy()
+
+
+def save_scene(path, spheres):
+    """Writes a scene dump (rth_scene_save): header + the 36-byte sphere records."""
+    s = np.ascontiguousarray(spheres, SPHERE_DTYPE)
+    rc = N.host.rth_scene_save(os.fsencode(path), s.ctypes.data, len(s))
+    if rc != 0:
+        raise ValueError(f"rth_scene_save: error {rc}: {N.host.rth_last_error().decode()}")
+
+
+def load_scene(path):
+    """Reads a scene dump (rth_scene_load) into a structured array."""
+    ptr, n = C.c_void_p(), C.c_size_t()
+    rc = N.host.rth_scene_load(os.fsencode(path), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise ValueError(f"rth_scene_load: error {rc}: {N.host.rth_last_error().decode()}")
+    try:
+        return np.frombuffer(C.string_at(ptr.value, n.value * SPHERE_DTYPE.itemsize), SPHERE_DTYPE).copy()
+    finally:
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        libc.free(ptr)
 
 
 def build_scene(which):

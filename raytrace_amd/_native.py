@@ -120,6 +120,8 @@ HOST_SYMBOLS = {
     "rth_scene_random": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(RthRng)]),
     "rth_scene_glass": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(RthRng)]),
     "rth_scene_build": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rth_scene_save": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
+    "rth_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "rth_write_ppm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "rth_write_png": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "rth_raytrace": (C.c_int, [C.POINTER(RtCamera), C.c_void_p, C.c_size_t, C.POINTER(RthRenderOpts), C.c_void_p,

@@ -10,6 +10,8 @@
  *     -x <width> -y <height>   image size (default 600x300)
  *     -s small|final|dense|glass|trivial   scene (default small, as the reference renders)
  *     -d <max depth>  -S <seed>
+ *     -i <scene file>       render a scene dump (rth_scene_load) instead of a built-in scene
+ *     -D <scene file>       also write the scene that is rendered as a scene dump
  * PPM and PNG are written (the PNG by the host library's own stored-deflate
  * encoder); JPG in the reference comes from a vendored third-party encoder
  * and is outside this path.
@@ -28,7 +30,8 @@ static const char *argv0;
 static void usage(void) {
   fprintf(stderr,
           "Usage: %s [-n <number of samples>] [-t <number of GPUs>] [-x <width>] [-y <height>]\n"
-          "          [-s small|final|dense|glass|trivial] [-d <max depth>] [-S <seed>] -o <output file>.<ppm/png>\n"
+          "          [-s small|final|dense|glass|trivial | -i <scene file>] [-D <scene file>] [-d <max depth>] [-S <seed>]\n"
+          "          -o <output file>.<ppm/png>\n"
           "\n"
           "If <output file> is '-' then a ppm image is written on stdout.\n"
           "\n"
@@ -63,8 +66,9 @@ int main(int argc, char **argv) {
   o.max_depth = 50;                /* c/main.c:262 */
   o.tile_rows = 8;
   int which = RTH_SCENE_SMALL;     /* what c/main.c:499 renders */
+  const char *scene_in = NULL, *scene_out = NULL;
   int opt;
-  while ((opt = getopt(argc, argv, "o:n:t:x:y:s:d:S:")) != -1) {
+  while ((opt = getopt(argc, argv, "o:n:t:x:y:s:d:S:i:D:")) != -1) {
     switch (opt) {
     case 'o': {
       if (strcmp(optarg, "-") == 0) { fp = stdout; break; }
@@ -86,6 +90,8 @@ int main(int argc, char **argv) {
     case 'x': o.nx = (uint32_t)positive("width", optarg); break;
     case 'y': o.ny = (uint32_t)positive("height", optarg); break;
     case 'd': o.max_depth = (uint32_t)positive("max depth", optarg); break;
+    case 'i': scene_in = optarg; break;
+    case 'D': scene_out = optarg; break;
     case 'S': o.seed = (uint32_t)strtoul(optarg, NULL, 10); break;
     case 's':
       if (!strcmp(optarg, "small")) which = RTH_SCENE_SMALL;
@@ -102,7 +108,16 @@ int main(int argc, char **argv) {
 
   rt_sphere *spheres = NULL;
   size_t n = 0;
-  if (rth_scene_build(which, &spheres, &n) != RT_OK) { fprintf(stderr, "could not build the scene\n"); return 1; }
+  if (scene_in) {
+    if (rth_scene_load(scene_in, &spheres, &n) != RT_OK) { fprintf(stderr, "could not load %s: %s\n", scene_in, rth_last_error()); return 1; }
+  } else if (rth_scene_build(which, &spheres, &n) != RT_OK) {
+    fprintf(stderr, "could not build the scene\n");
+    return 1;
+  }
+  if (scene_out && rth_scene_save(scene_out, spheres, n) != RT_OK) {
+    fprintf(stderr, "could not write %s: %s\n", scene_out, rth_last_error());
+    return 1;
+  }
   rt_camera cam;
   rth_camera_default(o.nx, o.ny, &cam);
   uint8_t *img = (uint8_t *)malloc((size_t)3 * o.nx * o.ny);  /* heap, not the reference's stack VLA (c/main.c:504-505) */

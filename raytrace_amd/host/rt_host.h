@@ -44,6 +44,13 @@ enum { RTH_SCENE_SMALL = 0, RTH_SCENE_FINAL = 1, RTH_SCENE_DENSE = 2, RTH_SCENE_
 /* allocates with malloc; caller frees */
 int rth_scene_build(int which, rt_sphere **out, size_t *n);
 
+/* Scene dump: a scene as a file, so that a fixture or a caller's scene can be rendered without its builder.
+ * Little-endian: the 8 bytes "RTSCENE1", uint32 record size (36), uint32 count, then count records laid out as
+ * rt_sphere (centre, radius, type, albedo, param: the sphere + material of c/structs.c:16-36).  rth_scene_load
+ * allocates with malloc (caller frees) and rejects a file whose size, record size or material types are off. */
+int rth_scene_save(const char *path, const rt_sphere *spheres, size_t n);
+int rth_scene_load(const char *path, rt_sphere **out, size_t *n);
+
 /* ppm_write, c/main.c:410-415 */
 int rth_write_ppm(FILE *fp, const uint8_t *rgb8, size_t w, size_t h);
 /* c/main.c:427-433: 8-bit RGB PNG (stored, i.e. uncompressed, deflate blocks) */

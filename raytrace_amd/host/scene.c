@@ -187,6 +187,52 @@ int rth_scene_build(int which, rt_sphere **out, size_t *n) {
   return RT_OK;
 }
 
+static const char kSceneMagic[8] = {'R', 'T', 'S', 'C', 'E', 'N', 'E', '1'};
+
+int rth_scene_save(const char *path, const rt_sphere *spheres, size_t n) {
+  if (!path || !spheres || n == 0 || n > 0xffffffffu) { rth_set_error("null or empty argument"); return RT_ERR_ARG; }
+  FILE *fp = fopen(path, "wb");
+  if (!fp) { rth_set_error("could not open the scene file for writing"); return RT_ERR_ARG; }
+  const uint32_t head[2] = {(uint32_t)sizeof(rt_sphere), (uint32_t)n};
+  int ok = fwrite(kSceneMagic, 1, sizeof kSceneMagic, fp) == sizeof kSceneMagic && fwrite(head, sizeof head[0], 2, fp) == 2 &&
+           fwrite(spheres, sizeof *spheres, n, fp) == n;
+  if (fclose(fp) != 0) ok = 0;
+  if (!ok) { rth_set_error("could not write the scene file"); return RT_ERR_ARG; }
+  return RT_OK;
+}
+
+int rth_scene_load(const char *path, rt_sphere **out, size_t *n) {
+  if (!path || !out || !n) { rth_set_error("null argument"); return RT_ERR_ARG; }
+  *out = NULL;
+  *n = 0;
+  FILE *fp = fopen(path, "rb");
+  if (!fp) { rth_set_error("could not open the scene file"); return RT_ERR_ARG; }
+  char magic[8];
+  uint32_t head[2];
+  int rc = RT_OK;
+  rt_sphere *s = NULL;
+  if (fread(magic, 1, sizeof magic, fp) != sizeof magic || memcmp(magic, kSceneMagic, sizeof magic) != 0 ||
+      fread(head, sizeof head[0], 2, fp) != 2 || head[0] != sizeof(rt_sphere) || head[1] == 0) {
+    rth_set_error("not a scene file of this format");
+    rc = RT_ERR_ARG;
+  }
+  if (rc == RT_OK) {
+    s = (rt_sphere *)malloc((size_t)head[1] * sizeof *s);
+    if (!s) { rth_set_error("out of host memory"); rc = RT_ERR_NOMEM; }
+  }
+  if (rc == RT_OK && (fread(s, sizeof *s, head[1], fp) != head[1] || fgetc(fp) != EOF)) {
+    rth_set_error("the scene file's length does not match its count");
+    rc = RT_ERR_ARG;
+  }
+  for (uint32_t i = 0; rc == RT_OK && i < head[1]; ++i)
+    if (s[i].type < 0 || s[i].type > 2) { rth_set_error("the scene file holds an unknown material type"); rc = RT_ERR_ARG; }
+  fclose(fp);
+  if (rc != RT_OK) { free(s); return rc; }
+  *out = s;
+  *n = head[1];
+  return RT_OK;
+}
+
 int rth_write_ppm(FILE *fp, const uint8_t *rgb8, size_t w, size_t h) {
   if (!fp || !rgb8) return RT_ERR_ARG;
   if (fprintf(fp, "P6\n%zu %zu 255\n", w, h) < 0) return RT_ERR_ARG;          /* c/main.c:412 */

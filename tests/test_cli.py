@@ -58,3 +58,34 @@ def test_cli_renders_the_bytes_of_the_oracle(tmp_path, rt, oracle):
     rows = np.frombuffer(zlib.decompress(raw[41:41 + n]), np.uint8).reshape(100, 601)
     assert np.array_equal(rows[:, 1:].reshape(100, 200, 3), want)
 
+
+
+def test_scene_file_errors_are_reported(tmp_path):
+    p = run("-i", str(tmp_path / "missing.bin"), "-o", "-")
+    assert p.returncode == 1 and b"could not load" in p.stderr
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"P6\n1 1 255\n")
+    p = run("-i", str(bad), "-o", "-")
+    assert p.returncode == 1 and b"not a scene file" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_renders_a_scene_dump(tmp_path, rt, oracle):
+    """-D writes the scene that was rendered; -i renders such a file: a caller's own sphere list, here the final
+    scene with a few spheres moved, against the oracle's picture of the same list."""
+    dump = tmp_path / "final.bin"
+    p = run("-s", "final", "-x", "64", "-y", "36", "-n", "1", "-D", str(dump), "-o", "-")
+    assert p.returncode == 0, p.stderr
+    sc = rt.load_scene(str(dump))
+    assert sc.tobytes() == rt.random_scene().tobytes()
+    sc["center"][5:9, 1] += 0.5
+    sc["type"][7] = 2
+    sc["param"][7] = 1.5
+    mine = tmp_path / "mine.bin"
+    rt.save_scene(str(mine), sc)
+    p = run("-i", str(mine), "-x", "160", "-y", "90", "-n", "3", "-t", "2", "-o", "-")
+    assert p.returncode == 0, p.stderr
+    from conftest import as_oracle_scene
+    want = oracle.render_det(rt.camera_default(160, 90).as_array(), as_oracle_scene(sc), 160, 90, 3, seed=0, host_threads=16,
+                             want_debug=False)["rgb8"]
+    assert p.stdout == b"P6\n160 90 255\n" + want.tobytes()

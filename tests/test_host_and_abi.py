@@ -6,6 +6,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -76,6 +77,30 @@ def test_bad_arguments_are_errors_not_aborts(rt):
     assert d.rt_scene_upload(None, None, 0) == 1
     assert d.rt_render_host(None, None, None, None, None, None, None) == 1
     assert d.rt_ctx_destroy(None) == 0
+
+
+def test_scene_dump_round_trip_and_rejections(rt, tmp_path):
+    """The scene dump format: what is saved is what is loaded, byte for byte (sphere + material of c/structs.c:16-36);
+    truncated, over-long, foreign and bad-material files are errors."""
+    import struct
+    for sc in (rt.small_scene(), rt.random_scene(), rt.glass_scene()):
+        path = str(tmp_path / f"scene_{len(sc)}.bin")
+        rt.save_scene(path, sc)
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"RTSCENE1" and struct.unpack("<II", raw[8:16]) == (36, len(sc)) and len(raw) == 16 + 36 * len(sc)
+        assert raw[16:] == sc.tobytes()
+        assert rt.load_scene(path).tobytes() == sc.tobytes()
+    good = open(path, "rb").read()
+    bad_type = bytearray(good)
+    bad_type[16 + 16:16 + 20] = struct.pack("<i", 7)                     # first record's material type
+    for name, blob in (("short", good[:-5]), ("long", good + b"x"), ("magic", b"P6\n" + good[3:]), ("empty", b""),
+                       ("record", good[:8] + struct.pack("<II", 32, 5) + good[16:]), ("type", bytes(bad_type))):
+        p = str(tmp_path / f"bad_{name}.bin")
+        open(p, "wb").write(blob)
+        with pytest.raises(ValueError):
+            rt.load_scene(p)
+    with pytest.raises(ValueError):
+        rt.load_scene(str(tmp_path / "missing.bin"))
 
 
 def test_png_writer_produces_a_decodable_image(rt, tmp_path):
