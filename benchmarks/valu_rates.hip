@@ -1,0 +1,111 @@
+// Throughput of vector instructions and of mixes of them on gfx950: four waves per SIMD, eight independent chains per wave,
+// cycles from s_memtime inside the kernel.  Build: hipcc -O3 --offload-arch=gfx950 -o valu_rates benchmarks/valu_rates.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define CHK(e) do { hipError_t r = (e); if (r != hipSuccess) { printf("%s: %s\n", #e, hipGetErrorString(r)); return 1; } } while (0)
+template <int OP>
+__global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters) {
+  uint32_t a[8]; double dd[8];
+  for (int i = 0; i < 8; ++i) { a[i] = seed + threadIdx.x * 8 + i; dd[i] = 1.0 + 1e-9 * a[i]; }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (OP == 0 && (r * 8 + i) % 2 == 0) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 0 && (r * 8 + i) % 2 == 1) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 1 && (r * 8 + i) % 2 == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 1 && (r * 8 + i) % 2 == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 2 && (r * 8 + i) % 2 == 0) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 2 && (r * 8 + i) % 2 == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 3 && (r * 8 + i) % 2 == 0) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 3 && (r * 8 + i) % 2 == 1) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 4 && (r * 8 + i) % 2 == 0) asm volatile("v_pk_fma_f32 %2, %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 4 && (r * 8 + i) % 2 == 1) asm volatile("v_pk_fma_f32 %2, %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 5 && (r * 8 + i) % 2 == 0) asm volatile("v_pk_fma_f32 %2, %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 5 && (r * 8 + i) % 2 == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 6 && (r * 8 + i) % 2 == 0) asm volatile("v_pk_fma_f32 %2, %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 6 && (r * 8 + i) % 2 == 1) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 7 && (r * 8 + i) % 2 == 0) asm volatile("v_pk_fma_f32 %2, %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 7 && (r * 8 + i) % 2 == 1) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 8 && (r * 8 + i) % 2 == 0) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 8 && (r * 8 + i) % 2 == 1) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 9 && (r * 8 + i) % 2 == 0) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 9 && (r * 8 + i) % 2 == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 10 && (r * 8 + i) % 3 == 0) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 10 && (r * 8 + i) % 3 == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 10 && (r * 8 + i) % 3 == 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 11 && (r * 8 + i) % 4 == 0) asm volatile("v_pk_fma_f32 %2, %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 11 && (r * 8 + i) % 4 == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 11 && (r * 8 + i) % 4 == 2) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 11 && (r * 8 + i) % 4 == 3) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 12 && (r * 8 + i) % 2 == 0) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 12 && (r * 8 + i) % 2 == 1) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 13 && (r * 8 + i) % 2 == 0) asm volatile("v_pk_mul_f32 %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 13 && (r * 8 + i) % 2 == 1) asm volatile("v_pk_mul_f32 %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 14 && (r * 8 + i) % 2 == 0) asm volatile("v_pk_add_f32 %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 14 && (r * 8 + i) % 2 == 1) asm volatile("v_pk_add_f32 %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 15 && (r * 8 + i) % 2 == 0) asm volatile("v_fma_f64 %2, %2, %2, %2" : "+v"(a[i]) , "+v"(a[(i+2)&7]), "+v"(dd[i]));
+        if (OP == 15 && (r * 8 + i) % 2 == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 16 && (r * 8 + i) % 2 == 0) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]) : "vcc");
+        if (OP == 16 && (r * 8 + i) % 2 == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 17 && (r * 8 + i) % 2 == 0) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 17 && (r * 8 + i) % 2 == 1) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 18 && (r * 8 + i) % 2 == 0) asm volatile("v_lshrrev_b32 %0, 16, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+        if (OP == 18 && (r * 8 + i) % 2 == 1) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  uint32_t s = 0;
+  for (int i = 0; i < 8; ++i) s ^= a[i] ^ (uint32_t)dd[i];
+  if (s == 0x12345u) out[0] = s;
+  out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(t1 - t0);
+}
+template <int OP>
+int run(const char *name, uint32_t *d) {
+  const int iters = 40000, blocks = 256 * 4;   // 4 workgroups of 4 waves per CU: 4 waves per SIMD
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 12345u, 10);
+  CHK(hipDeviceSynchronize());
+  CHK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 12345u, iters);
+  CHK(hipEventRecord(e1));
+  CHK(hipEventSynchronize(e1));
+  float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+  // wave-instructions per SIMD: 4 waves x iters x 64
+  double per_simd = 4.0 * iters * 64.0;
+  static uint32_t host[256 * 4 * 256];
+  CHK(hipMemcpy(host, d, sizeof host, hipMemcpyDeviceToHost));
+  double cyc = 0; for (int i = 0; i < 256 * 4 * 256; i += 64) cyc += host[i]; cyc /= (256 * 4 * 4);
+  printf("in-kernel: %.3f cycles per wave-instruction per SIMD (4 waves); clock %.2f GHz | ", cyc / (iters * 64.0) / 4.0, cyc / (ms * 1e6));
+  printf("%-18s %8.3f ms  -> %.2f ns per wave-instruction per SIMD (x2.4 GHz = %.2f cycles)\n", name, ms, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);
+  return 0;
+}
+int main() {
+  uint32_t *d; CHK(hipMalloc(&d, 256 * 4 * 256 * 4));
+  run<0>("warm", d);
+  run<0>("fma|fma", d);
+  run<1>("add|add", d);
+  run<2>("fma|add", d);
+  run<3>("fma|xor", d);
+  run<4>("pkfma|pkfma", d);
+  run<5>("pkfma|add", d);
+  run<6>("pkfma|xor", d);
+  run<7>("pkfma|mul_lo", d);
+  run<8>("mul_lo|xor", d);
+  run<9>("max|add", d);
+  run<10>("fma|add|add", d);
+  run<11>("pkfma|add|xor|mul", d);
+  run<12>("fmac(vop2)", d);
+  run<13>("pk_mul", d);
+  run<14>("pk_add", d);
+  run<15>("f64fma|add", d);
+  run<16>("cmp|add", d);
+  run<17>("sub|mul", d);
+  run<18>("lshr|xor", d);
+  return 0;
+}

@@ -53,7 +53,9 @@ using namespace rtcore;
 #else
 #define RT_ASM asm
 #endif
-// RT_EXP 31..39: the profiling build's "drain" column shows one stage of the shading phase instead
+// RT_EXP 39: every part of a trip counts the lanes it had at work and the times it ran (thread efficiency by
+// part); the sums land in the first words of the wave-log area (rt_debug_wave_log)
+// RT_EXP 31..34: the profiling build's "drain" column shows one stage of the shading phase instead
 // (31 rejection loop, 32 shading before it, 33 new paths, 34 shading after it)
 #define RT_STAGE_BEGIN(N) const unsigned long long stage_t0_##N = (RT_EXP == N && kProfile) ? tick() : 0ull
 #define RT_STAGE_END(N) \
@@ -147,6 +149,9 @@ struct HitState {
   uint32_t own_groups;   // groups this lane's own ray needed (diagnostic: what a per-ray cull would scan)
   uint32_t wave_groups;  // groups the wave scanned
   unsigned long long drain_cycles;   // shader cycles in the closing drain (profiling builds only)
+#if RT_EXP == 39
+  uint32_t fill[6];   // lanes at work and passes run: pair-filter passes, drain passes, always-group steps
+#endif
 };
 
 __device__ __forceinline__ FilterRay dead_ray() {
@@ -242,6 +247,10 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
 #endif
   for (uint32_t e0 = 0; e0 < w.wcnt; e0 += 64u) {
     const uint32_t e = e0 + w.lane;
+#if RT_EXP == 39
+    h.fill[2] += min(64u, w.wcnt - e0);
+    h.fill[3] += 1u;
+#endif
     if (e < w.wcnt) {
       const uint32_t entry = *(lds_u32 *)(uintptr_t)(w.wlist_off + (e << 2));
       const uint32_t owner = entry >> 16;
@@ -548,6 +557,10 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
     // first word of this lane's entries: owner | scan position of the group's first sphere
     const uint32_t word0 = (owner << 16) | (base + grp * kChunk);
     const unsigned long long valid_mask = __ballot(valid);   // (a scalar AND per sphere instead of a vector select)
+#if RT_EXP == 39
+    h.fill[0] += (uint32_t)__popcll(valid_mask);
+    h.fill[1] += 1u;
+#endif
     // Eight compares into eight scalar masks, OR-ed on the scalar unit, one branch
     // for the whole pass: no branch waits on a vector compare of its own.
     unsigned long long m[kChunk] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
@@ -664,6 +677,10 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
       for (uint32_t half = 0; half < 2u; ++half) {
         if (half == 1u && real <= (uint32_t)(kChunk / 2)) break;
         if (w.wcnt + 64u * (kChunk / 2) > kWaveListCapCull) drain_wave(sc, w, h);
+#if RT_EXP == 39
+        h.fill[4] += (uint32_t)__popcll(own_mask);
+        h.fill[5] += 1u;
+#endif
         const float4 *src = lds_pairs + g * kChunk + 4u * half;
         const float4 q[4] = {src[0], src[1], src[2], src[3]};
         f32x2 d[2];
@@ -999,6 +1016,19 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   uint32_t lane_tests = 0;                    // sphere tests this lane evaluated (culled scan), summed over the wave at the end
   unsigned long long n_own = 0, n_wave = 0;   // per lane, profiling builds only
   unsigned long long c_scan = 0, c_drain = 0, c_shade = 0;
+#if RT_EXP == 39
+  // lanes at work / times executed, per part of the trip (wave-uniform counts)
+  uint32_t fill[24] = {};
+  uint32_t lane_tries = 0;
+#define RT_FILL(K, MASK)                                   \
+  do {                                                     \
+    const unsigned long long fill_m = (MASK);              \
+    fill[K] += (uint32_t)__popcll(fill_m);                 \
+    fill[(K) + 1] += fill_m != 0ull ? 1u : 0u;             \
+  } while (0)
+#else
+#define RT_FILL(K, MASK) do { } while (0)
+#endif
   const unsigned long long c_begin = kProfile ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long r_begin = kProfile ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
@@ -1034,9 +1064,16 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
         n_tests += (unsigned long long)h.scan_tests * live;
         n_box += (unsigned long long)h.box_tests * live;
         lane_tests += h.lane_tests;
+#if RT_EXP == 39
+        for (int k = 0; k < 6; ++k) fill[k] += h.fill[k];
+        fill[6] += live;
+        fill[7] += 1u;
+#endif
       }
       // ---- (2): shade, first part
       RT_STAGE_BEGIN(32);
+      RT_FILL(8, __ballot(alive && h.index >= 0));
+      RT_FILL(12, __ballot(alive && h.index < 0));
       if (alive) {
         if (kProfile) {
           n_own += h.own_groups;
@@ -1057,6 +1094,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
           const double inv_r = __hiloint2double(__float_as_int(tail.y), __float_as_int(tail.x));
           const V3 pc = p - v3(e.x, e.y, e.z);
           n = v3(div_f32_by(pc.x, e.w, inv_r), div_f32_by(pc.y, e.w, inv_r), div_f32_by(pc.z, e.w, inv_r));   // c/main.c:229
+          RT_FILL(10, __ballot(type == RT_DIELECTRIC));
           if (type == RT_DIELECTRIC) {
             // (a dielectric has no albedo -- attenuation 1, c/main.c:183 -- and its record carries r0 and 1 / idx there)
             B = scatter_dielectric_unit(B, unitB, lenB, n, m4.w, m4.x, m4.y, g);
@@ -1157,10 +1195,25 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
       pool_next += min((uint32_t)__popcll(idle_mask), avail);
     }
     RT_STAGE_END(33);
+    RT_FILL(14, __ballot(pending == kNewPath));
     // ---- (4): the point in the unit ball
     V3 ball = v3(0, 0, 0);
     RT_STAGE_BEGIN(31);
+#if RT_EXP == 39
+    {
+      // (lane-tries counted per lane: every lane still looking makes one try per trip of the loop)
+      bool looking = pending != kNone;
+      while (wave_any(looking)) {
+        fill[17] += 1u;
+        if (looking) {
+          lane_tries++;
+          looking = !unit_ball_try(g, ball);
+        }
+      }
+    }
+#else
     if (pending != kNone) ball = unit_ball(g);
+#endif
 #if RT_EXP == 14   // the rejection loop a second time, from a generator state that gives other trip counts
     if (pending != kNone) {
       Rng g2{g.x ^ 0x5bd1e995u};
@@ -1171,6 +1224,9 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
     RT_STAGE_END(31);
     // ---- (5): shade, second part / camera ray
     RT_STAGE_BEGIN(34);
+    RT_FILL(18, __ballot(pending == kNewPath));
+    RT_FILL(20, __ballot(pending == kMatte));
+    RT_FILL(22, __ballot(pending == kMetal));
     if (pending == kNewPath) {
       const Camera cam = kernarg_now<Camera>(offsetof(TraceArgs, cam));
       camera_ray_from(cam, p.x, p.y, ball, A, B);
@@ -1233,6 +1289,12 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
       atomicAdd(&args.counters[12], w_wave);
     }
   }
+#if RT_EXP == 39
+  fill[16] = (uint32_t)wave_sum((unsigned long long)lane_tries);
+  if (lane == 0 && args.counters)
+    for (int k = 0; k < 24; ++k) atomicAdd(&args.counters[kWaveLogBase + k], (unsigned long long)fill[k]);
+#endif
+#undef RT_FILL
   // event counts: one atomic per wave and counter
   n_tests += wave_sum((unsigned long long)lane_tests);
   if (lane == 0 && args.counters) {
@@ -1902,8 +1964,8 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Work
   t.counters = ws.counters;
   const bool cull_scan = (job->flags & RT_FLAG_FULL_SCAN) == 0;
   size_t lds = trace_lds_bytes(c->n_pad, cull_scan);
-#if RT_EXP == 41   // occupancy experiment: pad the LDS request so that only three workgroups fit a CU
-  lds += 10240;
+#if RT_EXP >= 41 && RT_EXP <= 43   // occupancy experiment: an LDS request of which only three (41), four (42) or two (43) fit a CU
+  lds = RT_EXP == 41 ? 53760 : RT_EXP == 42 ? 40960 : 65536;
 #endif
   const bool batched = c->n_pad > kMaxLdsSpheres, profile = (job->flags & RT_FLAG_PROFILE) != 0;
   const void *kernel_fn = trace_kernel_fn(batched, cull_scan, profile);
