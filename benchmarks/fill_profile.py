@@ -30,7 +30,7 @@ job = rt.Job(1920, 1080, spp, seed=0)
 
 
 def words():
-    log = np.zeros(24, np.uint64)
+    log = np.zeros(28, np.uint64)
     rt.N.check(rt.N.device.rt_debug_wave_log(r._h, C.c_void_p(log.ctypes.data), len(log)), "wave_log")
     return log.astype(np.float64)
 
@@ -46,4 +46,8 @@ for name, k in zip(PARTS, ORDER):
     lanes, runs = d[k], d[k + 1]
     out["parts"].append({"part": name, "runs_per_trip": runs / c["wave_iterations"], "lanes_per_run": lanes / max(1.0, runs),
                          "thread_efficiency": lanes / max(1.0, 64.0 * runs)})
+out["batch_visits_per_trip"] = d[24] / c["wave_iterations"]
+out["batches_picked_per_trip"] = d[25] / c["wave_iterations"]
+out["lane_batch_pairs_wanted_per_trip"] = d[26] / c["wave_iterations"]
+out["batches_wanted_by_some_lane_per_trip"] = d[27] / c["wave_iterations"]
 print(json.dumps(out, indent=1))

@@ -350,6 +350,28 @@ RT_HD f32x2 filter_discriminant2(const FilterRay2 &f, f32x2 cx, f32x2 cy, f32x2 
 // would leave the range), |B|^2 >= 2^40 or |A|^2 >= 2^40 are not culled at all
 // (box_ray_in_range).
 
+// Distance cut (streamed scans of large scenes).  Once a ray has a hit at t_best, a box whose computed
+// near bound max_k near_k exceeds
+//   cut = t_best (1 + 2^-8) + 2^-7 (reach_max + b_max (|A|^2 + 1)) / |B|
+// holds no sphere the reference would report nearer, and is skipped.  Why: let the reference report the
+// root t_c for a sphere behind that box.  The quantities b, c, D of c/main.c:216-219 are float
+// evaluations of the true b*, c*, D* with |b - b*| <= 4u |oc| |B| and |D - D*| <= (19u |oc|^2 + 7u r^2) |B|^2
+// (u = 2^-24), so the root differs from a parameter t' of the TRUE line -- the true root where D* >= 0,
+// else the closest approach, which the filter's margin keeps within rho_i of the centre -- by at most
+// (2^-9.9 |oc| + 2^-10.6 r) / |B| (from |sqrt(D) - sqrt(D*)| <= sqrt|D - D*|); the double-precision root and
+// its narrowing add 2^-24 relative.  The point at t' lies in the ball of radius rho_i <= reach_i + b_i |A|^2 +
+// 2^-21 |A| the box was built around, so the computed near bound is at most t' (the box test's own
+// argument above: computed bounds bracket every point of that ball), and |oc| <= |B| t' + 2 rho_i.
+// Together: near <= t' <= t_c (1 + 2^-9.7) + 2^-8.5 rho_i / |B|.  A box with near > cut therefore has
+// t_c > t_best for every sphere in it -- strictly, so the lowest-index rule for equal t is not touched.
+// t' < 0 gives near < 0 <= cut: never skipped.  NaN bounds compare false and are not skipped.
+constexpr float kCutRel = 1.00390625f;      // 1 + 2^-8
+constexpr float kCutAbs = 0.0078125f;       // 2^-7
+// the part of `cut` that does not depend on the hit: inv_len >= 1 / |B|
+RT_HD float cut_slack(float reach_max, float b_max, float a2, float inv_len) {
+  return kCutAbs * (reach_max + b_max * (a2 + 1.0f)) * inv_len * 1.001f;
+}
+
 struct GroupBox {  // centre and half extents; h = +1e30: always scanned, h = -1e30: never (padding)
   float cx, cy, cz, hx, hy, hz;
 };

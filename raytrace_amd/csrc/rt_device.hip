@@ -112,6 +112,7 @@ struct DeviceScene {
   const uint8_t *group_real;   // n_pad/8 entries: real (non-pad) spheres per group
   uint32_t n, n_pad;
   float sigma0, sigma1;   // per-ray growth of the group boxes (rt_core.h, rt_cluster.h)
+  float cut_reach, cut_b; // constants of the distance cut (rtcore::cut_slack)
   uint32_t n_full;        // scan positions up to the last real sphere, rounded up to a round (16): what a
                           // scan without culling has to visit (the rest is padding)
   uint32_t n_always_groups;   // the first so many groups go on every ray's list untested; their entries in
@@ -138,6 +139,22 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   return v;
 }
 
+// smallest v of the wave's 64 lanes (all lanes active): four steps inside each row of 16 lanes, two across rows
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float wave_min_step(float x) {
+  const int y = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), kCtrl, kRowMask, 0xf, false);
+  return __builtin_fminf(x, __int_as_float(y));
+}
+__device__ __forceinline__ float wave_min(float v) {
+  v = wave_min_step<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v = wave_min_step<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+  v = wave_min_step<0x141, 0xf>(v);   // row_half_mirror
+  v = wave_min_step<0x140, 0xf>(v);   // row_mirror: every lane of a row holds the row's minimum
+  v = wave_min_step<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+  v = wave_min_step<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds the minimum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Result of one closest-hit query of a lane.
 struct HitState {
   float closest;    // smallest t (the query's tmax while there is no hit)
@@ -150,7 +167,7 @@ struct HitState {
   uint32_t wave_groups;  // groups the wave scanned
   unsigned long long drain_cycles;   // shader cycles in the closing drain (profiling builds only)
 #if RT_EXP == 39
-  uint32_t fill[6];   // lanes at work and passes run: pair-filter passes, drain passes, always-group steps
+  uint32_t fill[10];   // lanes at work and passes run: pair-filter passes, drain passes, always-group steps; [6] batch visits, [7] batches picked (streamed scenes)
 #endif
 };
 
@@ -389,8 +406,10 @@ __device__ __forceinline__ BoxRayP pack_box_ray(const BoxRay &r) {
   return b;
 }
 
-// pass[i] = box i of the round is met by the lane's half line; q = the round's three LDS entries
-__device__ __forceinline__ void box_pair(const BoxRayP &r, const float4 (&q)[3], bool (&pass)[2]) {
+// pass[i] = box i of the round is met by the lane's half line; q = the round's three LDS entries.
+// kCut: ... and not farther along it than `cut` (rtcore: distance cut)
+template <bool kCut = false>
+__device__ __forceinline__ void box_pair(const BoxRayP &r, const float4 (&q)[3], bool (&pass)[2], float cut = 0.0f) {
   const f32x2 cx = {q[0].x, q[0].y}, cy = {q[0].z, q[0].w}, cz = {q[1].x, q[1].y};
   const f32x2 hx = {q[1].z, q[1].w}, hy = {q[2].x, q[2].y}, hz = {q[2].z, q[2].w};
   f32x2 nx, ny, nz, fx, fy, fz, mx, my, mz;
@@ -412,7 +431,7 @@ __device__ __forceinline__ void box_pair(const BoxRayP &r, const float4 (&q)[3],
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx[i]), "v"(ny[i]), "v"(nz[i]));
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx[i]), "v"(fy[i]), "v"(fz[i]));
     asm("v_max_f32 %0, 0, %1" : "=v"(lim) : "v"(tn));
-    pass[i] = tf >= lim;
+    pass[i] = kCut ? (tf >= lim && !(tn > cut)) : tf >= lim;
   }
 }
 
@@ -422,7 +441,7 @@ struct BoxPairS {
   f32x2 cx, cy, cz, hx, hy, hz;
 };
 
-__device__ __forceinline__ void box_pair_scalar(const BoxRayP &r, const BoxPairS &b, bool (&pass)[2]) {
+__device__ __forceinline__ void box_pair_scalar(const BoxRayP &r, const BoxPairS &b, bool (&pass)[2], float *near_bound = nullptr) {
   f32x2 nx, ny, nz, fx, fy, fz, mx, my, mz;
   RT_ASM("v_pk_fma_f32 %6, %9, %14, %10 op_sel:[0,0,1] op_sel_hi:[0,1,1]\n\t"
          "v_pk_fma_f32 %7, %9, %15, %11 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
@@ -443,6 +462,7 @@ __device__ __forceinline__ void box_pair_scalar(const BoxRayP &r, const BoxPairS
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx[i]), "v"(fy[i]), "v"(fz[i]));
     asm("v_max_f32 %0, 0, %1" : "=v"(lim) : "v"(tn));
     pass[i] = tf >= lim;
+    if (near_bound) near_bound[i] = tn;
   }
 }
 
@@ -629,10 +649,10 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
 // lane whose ray can touch a group puts (lane, group) on the wave's list, and
 // filter_listed_pairs does the rest.  `uncullable` lanes (rays outside the
 // range the boxes are valid for) list every group; lanes without a ray none.
-template <bool kCull>
+template <bool kCull, bool kCut = false>
 __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
                                            const FilterRayP &fr, const BoxRayP &br, bool alive, bool uncullable,
-                                           WaveScan &w, HitState &h) {
+                                           WaveScan &w, HitState &h, float cut = 0.0f) {
   const float4 *lds_pairs = lds.pairs, *lds_boxes = lds.boxes, *lds_sboxes = lds.sboxes;
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
   if (!kCull) {
@@ -717,7 +737,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
   {
     auto test_pair = [&](const float4 (&sq)[3], uint32_t pair_index) {
       bool spass[2];
-      box_pair(br, sq, spass);
+      box_pair<kCut>(br, sq, spass, cut);
       const unsigned long long s0 = (__ballot(spass[0]) & live_mask) | all_mask, s1 = (__ballot(spass[1]) & live_mask) | all_mask;
       // (two scalar selects; written as (s0 != 0 ? 1 : 0) the first one goes through a vector register)
       const unsigned long long bit = 1ull << (2u * pair_index);
@@ -754,7 +774,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     // than kept in registers across the filter pass.
     auto round2 = [&](const float4 (&q)[3], uint32_t i0, float4 (&ahead)[3], uint32_t ahead_first) {
       bool pass[2];
-      box_pair(br, q, pass);
+      box_pair<kCut>(br, q, pass, cut);
 #if RT_EXP == 13
       {
         bool pass2[2];
@@ -848,16 +868,16 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
     // need.  (Staging each batch into LDS for the whole workgroup, two barriers per batch, left the vector
     // ALUs idle 60 % of the time.)
     unsigned long long want_lo = ~0ull, want_hi = ~0ull;   // (without culling: every batch)
+    typedef __attribute__((address_space(4))) const float *ScalarFloats;
+    const ScalarFloats bb = (ScalarFloats)(uintptr_t)(sc.sboxes + 3u * (sc.n_pad / 64u));
+    auto load_pair = [&](uint32_t q) {
+      const ScalarFloats e = bb + 12u * q;
+      return BoxPairS{f32x2{e[0], e[1]}, f32x2{e[2], e[3]}, f32x2{e[4], e[5]}, f32x2{e[6], e[7]}, f32x2{e[8], e[9]}, f32x2{e[10], e[11]}};
+    };
+    const unsigned long long all_mask = __ballot(uncullable), live_mask = __ballot(alive);
     if (kCull) {
-      typedef __attribute__((address_space(4))) const float *ScalarFloats;
-      const ScalarFloats bb = (ScalarFloats)(uintptr_t)(sc.sboxes + 3u * (sc.n_pad / 64u));
       const uint32_t n_batch_pairs = batch_pairs(sc.n_pad);
-      const unsigned long long all_mask = __ballot(uncullable), live_mask = __ballot(alive);
       unsigned long long mine_lo = 0ull, mine_hi = 0ull;
-      auto load_pair = [&](uint32_t q) {
-        const ScalarFloats e = bb + 12u * q;
-        return BoxPairS{f32x2{e[0], e[1]}, f32x2{e[2], e[3]}, f32x2{e[4], e[5]}, f32x2{e[6], e[7]}, f32x2{e[8], e[9]}, f32x2{e[10], e[11]}};
-      };
       BoxPairS cur = load_pair(0u);
       for (uint32_t q = 0; q < n_batch_pairs; ++q) {
         const BoxPairS nxt = load_pair(q + 1u < n_batch_pairs ? q + 1u : 0u);
@@ -865,6 +885,10 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
         box_pair_scalar(br, cur, pass);
         const unsigned long long m0 = __ballot(pass[0]) & live_mask, m1 = __ballot(pass[1]) & live_mask;
         const unsigned long long bits = (unsigned long long)((m0 != 0ull ? 1u : 0u) | (m1 != 0ull ? 2u : 0u));
+#if RT_EXP == 39
+        h.fill[8] += (uint32_t)(__popcll(m0) + __popcll(m1));   // (lane, batch) pairs wanted
+        h.fill[9] += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);   // batches some lane wants
+#endif
         if (q < 32u) mine_lo |= bits << (2u * q);
         else mine_hi |= bits << (2u * q - 64u);
         cur = nxt;
@@ -875,22 +899,93 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       want_hi = mine_hi;
     }
     static_assert((kMaxSpheres + kBatchSpheres) / kBatchSpheres <= 128u, "two 64-bit masks");
+    auto visit = [&](uint32_t base, float cut) {
+      const uint32_t count = min(kBatchSpheres, sc.n_pad - base);
+      // (without culling the trailing padding is not visited)
+      const uint32_t span = kCull ? count : (sc.n_full > base ? min(count, sc.n_full - base) : 0u);
+      ScanLds in_place = lds;   // (the per-wave lists, rays and keys stay in LDS; the scene's arrays are the global ones)
+      in_place.pairs = const_cast<float4 *>(sc.filter + base);
+      in_place.boxes = const_cast<float4 *>(sc.boxes + 3u * (base / 16u));
+      in_place.sboxes = const_cast<float4 *>(sc.sboxes + 3u * (base / 64u));
+      in_place.real8 = const_cast<uint8_t *>(sc.group_real + base / 8u);
+      scan_batch<kCull, kCull>(sc, in_place, base, span, fr, br, alive, uncullable, w, h, cut);
+    };
+    if (kCull && live_mask != 0ull) {
+      // Near batches first, and every hit found narrows what is still worth a visit (rtcore: distance cut).
+      // Lane j holds the squared distance from the wave's first ray origin to the box of batch j (and of
+      // batch j + 64): the rays of a wave start close together, so this is near-to-far along each of them
+      // whichever way it points.  The wave takes the smallest key, tests that batch's box again -- now
+      // against each ray's cut -- scans it if some ray still wants it, evaluates what the scan listed,
+      // and moves each ray's cut up to its hit.  Batch 0 (the always-scanned large spheres live there:
+      // the ground ends most rays) goes first.
+      const uint32_t n_batches = 2u * batch_pairs(sc.n_pad);
+      const int rep = (int)__builtin_ctzll(live_mask);
+      const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.x), rep));
+      const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.y), rep));
+      const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.z), rep));
+      const float *boxes_flat = reinterpret_cast<const float *>(sc.sboxes + 3u * (sc.n_pad / 64u));
+      auto key_of = [&](uint32_t j, bool wanted) {
+        float key = __builtin_inff();
+        if (wanted && j < n_batches) {
+          const float *e = boxes_flat + 12u * (j >> 1) + (j & 1u);
+          const float dx = __builtin_fmaxf(__builtin_fabsf(ox - e[0]) - e[6], 0.0f);
+          const float dy = __builtin_fmaxf(__builtin_fabsf(oy - e[2]) - e[8], 0.0f);
+          const float dz = __builtin_fmaxf(__builtin_fabsf(oz - e[4]) - e[10], 0.0f);
+          key = dx * dx + dy * dy + dz * dz;
+          if (!(key < 1.0e30f)) key = 1.0e30f;   // (an always-scanned batch has no box: last, but visited)
+        }
+        return key;
+      };
+      float key0 = key_of(w.lane, ((want_lo >> w.lane) & 1ull) != 0ull);
+      float key1 = n_batches > 64u ? key_of(w.lane + 64u, ((want_hi >> w.lane) & 1ull) != 0ull) : __builtin_inff();
+      if (w.lane == 0u && (want_lo & 1ull)) key0 = -1.0f;
+      // what a hit distance is raised by before it rules a box out; a ray outside the boxes' range is never cut
+      const float slack = cut_slack(sc.cut_reach, sc.cut_b, dot(A, A), __builtin_amdgcn_rsqf(a) * 1.001f);
+      float cut = __builtin_inff();
+      for (;;) {
+        const float k = __builtin_fminf(key0, key1);
+        const float kmin = wave_min(k);
+        if (!(kmin < __builtin_inff())) break;
+        const int j = (int)__builtin_ctzll(__ballot(k == kmin));
+        const bool second = __builtin_amdgcn_readlane((key0 == kmin) ? 0 : 1, j) != 0;
+        if ((int)w.lane == j) {
+          if (second) key1 = __builtin_inff();
+          else key0 = __builtin_inff();
+        }
+#if RT_EXP == 39
+        h.fill[7] += 1u;
+#endif
+        const uint32_t bi = (uint32_t)j + (second ? 64u : 0u);
+        const uint32_t base = bi * kBatchSpheres;
+        if (base >= sc.n_pad) continue;
+        if (all_mask == 0ull) {
+          bool pass[2];
+          float near_bound[2];
+          box_pair_scalar(br, load_pair(bi >> 1), pass, near_bound);
+          const bool still = (bi & 1u) ? (pass[1] && !(near_bound[1] > cut)) : (pass[0] && !(near_bound[0] > cut));
+          h.box_tests += 2u;
+          if ((__ballot(still) & live_mask) == 0ull) continue;
+        }
+#if RT_EXP == 39
+        h.fill[6] += 1u;
+#endif
+        visit(base, cut);
+        if (w.wcnt != 0u) {
+          drain_wave(sc, w, h);
+          const float t_best = __uint_as_float((uint32_t)(lds.best[tid] >> 32));
+          cut = rt_fma(t_best, kCutRel, slack);
+        }
+      }
+    } else if (!kCull) {
 #pragma unroll 1
-    for (uint32_t half = 0; half < 2u; ++half) {
-      unsigned long long want = half ? want_hi : want_lo;
-      while (want != 0ull) {
-        const uint32_t base = (half * 64u + (uint32_t)__builtin_ctzll(want)) * kBatchSpheres;
-        want &= want - 1ull;
-        if (base >= sc.n_pad) break;   // (a mask with every bit set names batches that do not exist)
-        const uint32_t count = min(kBatchSpheres, sc.n_pad - base);
-        // (without culling the trailing padding is not visited)
-        const uint32_t span = kCull ? count : (sc.n_full > base ? min(count, sc.n_full - base) : 0u);
-        ScanLds in_place = lds;   // (the per-wave lists, rays and keys stay in LDS; the scene's arrays are the global ones)
-        in_place.pairs = const_cast<float4 *>(sc.filter + base);
-        in_place.boxes = const_cast<float4 *>(sc.boxes + 3u * (base / 16u));
-        in_place.sboxes = const_cast<float4 *>(sc.sboxes + 3u * (base / 64u));
-        in_place.real8 = const_cast<uint8_t *>(sc.group_real + base / 8u);
-        scan_batch<kCull>(sc, in_place, base, span, fr, br, alive, uncullable, w, h);
+      for (uint32_t half = 0; half < 2u; ++half) {
+        unsigned long long want = half ? want_hi : want_lo;
+        while (want != 0ull) {
+          const uint32_t base = (half * 64u + (uint32_t)__builtin_ctzll(want)) * kBatchSpheres;
+          want &= want - 1ull;
+          if (base >= sc.n_pad) break;   // (a mask with every bit set names batches that do not exist)
+          visit(base, 0.0f);
+        }
       }
     }
   } else {
@@ -927,9 +1022,15 @@ __device__ __forceinline__ uint32_t global_row(const rt_job &job, uint32_t lr, u
 // Every path's radiance goes to rad[s][pixel] (with its first-hit index in
 // the fourth word); resolve_kernel then adds each pixel's samples in sample
 // order, which is the reference's summation order (c/main.c:462-469).
-constexpr uint32_t kChunkItems = 512;
+#ifndef RT_CHUNK_ITEMS
+#define RT_CHUNK_ITEMS 512
+#endif
+#ifndef RT_TAIL_PATHS
+#define RT_TAIL_PATHS 4
+#endif
+constexpr uint32_t kChunkItems = RT_CHUNK_ITEMS;
 constexpr uint32_t kTailChunkItems = 64;      // chunk size for the last paths of a launch
-constexpr uint32_t kTailPathsPerLane = 4;     // how many paths per lane of the grid are handed out in small chunks
+constexpr uint32_t kTailPathsPerLane = RT_TAIL_PATHS;     // how many paths per lane of the grid are handed out in small chunks
 
 // image and queue geometry of a launch: what handing out new paths needs
 struct PathGeom {
@@ -1018,7 +1119,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   unsigned long long c_scan = 0, c_drain = 0, c_shade = 0;
 #if RT_EXP == 39
   // lanes at work / times executed, per part of the trip (wave-uniform counts)
-  uint32_t fill[24] = {};
+  uint32_t fill[28] = {};
   uint32_t lane_tries = 0;
 #define RT_FILL(K, MASK)                                   \
   do {                                                     \
@@ -1066,6 +1167,10 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
         lane_tests += h.lane_tests;
 #if RT_EXP == 39
         for (int k = 0; k < 6; ++k) fill[k] += h.fill[k];
+        fill[24] += h.fill[6];
+        fill[25] += h.fill[7];
+        fill[26] += h.fill[8];
+        fill[27] += h.fill[9];
         fill[6] += live;
         fill[7] += 1u;
 #endif
@@ -1292,7 +1397,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
 #if RT_EXP == 39
   fill[16] = (uint32_t)wave_sum((unsigned long long)lane_tries);
   if (lane == 0 && args.counters)
-    for (int k = 0; k < 24; ++k) atomicAdd(&args.counters[kWaveLogBase + k], (unsigned long long)fill[k]);
+    for (int k = 0; k < 28; ++k) atomicAdd(&args.counters[kWaveLogBase + k], (unsigned long long)fill[k]);
 #endif
 #undef RT_FILL
   // event counts: one atomic per wave and counter
@@ -1803,7 +1908,7 @@ struct rt_ctx {
   DevBuf<uint8_t> group_real;
   uint32_t n = 0, n_pad = 0, n_full = 0, n_always_groups = 0;
   std::map<std::pair<const void *, size_t>, int> blocks_per_cu;   // resident workgroups per CU of a trace kernel variant
-  float sigma0 = 0.0f, sigma1 = 0.0f;
+  float sigma0 = 0.0f, sigma1 = 0.0f, cut_reach = 0.0f, cut_b = 0.0f;
   DevBuf<unsigned long long> counters;
   DevBuf<unsigned int> queue;        // work-queue head of the trace kernel
   DevBuf<float4> rad[2];             // per-path radiance of one sample batch (two: see trace_stream)
@@ -1839,7 +1944,7 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->shade_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->n_full, c->n_always_groups};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->shade_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->cut_reach, c->cut_b, c->n_full, c->n_always_groups};
 }
 
 size_t scan_lds_bytes(uint32_t entries, bool cull) {
@@ -2346,6 +2451,8 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   c->n_always_groups = L.n_always_groups;
   c->sigma0 = L.sigma0;
   c->sigma1 = L.sigma1;
+  c->cut_reach = L.cut_reach;
+  c->cut_b = L.cut_b;
   uint32_t last_real = 0;
   for (uint32_t p = 0; p < n_pad; ++p)
     if (L.order[p] != 0xffffffffu) last_real = p;
