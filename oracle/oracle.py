@@ -92,6 +92,8 @@ class Oracle:
         L.orc_hit_sphere.argtypes = [C.c_void_p, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _fp]
         L.orc_hit_scene.restype = C.c_int
         L.orc_hit_scene.argtypes = [C.c_void_p, C.c_size_t, _fp, _fp, C.c_float, C.c_float, _fp, _fp, _fp]
+        L.orc_hit_scene_many.restype = C.c_int
+        L.orc_hit_scene_many.argtypes = [C.c_void_p, C.c_size_t, _fp, C.c_size_t, C.c_float, C.c_float, _i32p, _fp, C.c_size_t]
         L.orc_schlick.restype = C.c_float
         L.orc_schlick.argtypes = [C.c_float, C.c_float]
         L.orc_refract.restype = C.c_int
@@ -158,6 +160,16 @@ class Oracle:
         n = (C.c_float * 3)()
         idx = self.lib.orc_hit_scene(spheres.ctypes.data, len(spheres), _f3(A), _f3(B), tmin, tmax, C.byref(t), p, n)
         return idx, np.float32(t.value), np.array(p[:], np.float32), np.array(n[:], np.float32)
+
+    def hit_scene_many(self, spheres, rays, tmin=np.float32(0.001), tmax=np.finfo(np.float32).max, threads=16):
+        """hit_scene for every ray of rays[m, 6] (A, B): (index[m] int32 with -1 for no hit, t[m] float32)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        idx = np.full(len(rays), -1, np.int32)
+        t = np.zeros(len(rays), np.float32)
+        rc = self.lib.orc_hit_scene_many(spheres.ctypes.data, len(spheres), _ptr(rays, _fp), len(rays), tmin, tmax,
+                                         _ptr(idx, _i32p), _ptr(t, _fp), threads)
+        assert rc == 0
+        return idx, t
 
     # ---- renders ----
     def render_sequential(self, cam, spheres, nx, ny, nsamples, threads):

@@ -333,6 +333,43 @@ int orc_hit_scene(const orc_sphere *s, size_t n, const float A[3],
   return (int)(h.obj - s);
 }
 
+/* orc_hit_scene for m rays (6 floats each: A, B), rays dealt to `threads` pthreads; index[i] = -1 for no hit,
+ * t[i] written only on a hit.  The scan of each ray is scene_hit, c/main.c:239-258, unchanged. */
+typedef struct {
+  const orc_sphere *s; size_t n; const float *rays; size_t first, step, m; float tmin, tmax; int32_t *index; float *t;
+} many_job;
+
+static void *many_run(void *arg) {
+  many_job *j = (many_job *)arg;
+  for (size_t i = j->first; i < j->m; i += j->step) {
+    ray_t r = {f3_ld(j->rays + 6 * i), f3_ld(j->rays + 6 * i + 3)};
+    hit_t h;
+    uint64_t tests = 0;
+    if (scene_hit(j->s, j->n, &r, j->tmin, j->tmax, &h, &tests)) {
+      j->index[i] = (int32_t)(h.obj - j->s);
+      j->t[i] = h.t;
+    } else {
+      j->index[i] = -1;
+    }
+  }
+  return NULL;
+}
+
+int orc_hit_scene_many(const orc_sphere *s, size_t n, const float *rays, size_t m, float tmin, float tmax,
+                       int32_t *index, float *t, size_t threads) {
+  if (threads == 0) threads = 1;
+  pthread_t *tid = (pthread_t *)calloc(threads, sizeof *tid);
+  many_job *jobs = (many_job *)calloc(threads, sizeof *jobs);
+  if (!tid || !jobs) { free(tid); free(jobs); return -1; }
+  for (size_t k = 0; k < threads; k++) {
+    jobs[k] = (many_job){s, n, rays, k, threads, m, tmin, tmax, index, t};
+    pthread_create(&tid[k], NULL, many_run, &jobs[k]);
+  }
+  for (size_t k = 0; k < threads; k++) pthread_join(tid[k], NULL);
+  free(tid); free(jobs);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* materials: c/main.c:140-211 */
 

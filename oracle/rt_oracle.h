@@ -82,6 +82,9 @@ int orc_hit_sphere(const orc_sphere *s, const float A[3], const float B[3],
 int orc_hit_scene(const orc_sphere *s, size_t n, const float A[3],
                   const float B[3], float tmin, float tmax, float *t,
                   float p[3], float nrm[3]);
+/* the same scan for m rays (6 floats each), on `threads` pthreads; index -1 = no hit */
+int orc_hit_scene_many(const orc_sphere *s, size_t n, const float *rays, size_t m, float tmin, float tmax,
+                       int32_t *index, float *t, size_t threads);
 float orc_schlick(float cosine, float ref_idx);
 int orc_refract(const float u[3], const float n[3], float ni_over_nt,
                 float out[3]);

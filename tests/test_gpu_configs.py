@@ -113,3 +113,54 @@ def test_final_scene_rows_at_4k_1024spp(renderer, rt, oracle):
     got = renderer.render_host(cam, job)
     want = oracle_rows(oracle, cam, as_oracle_scene(sc), nx, ny, spp, 0, [1199, 2159])
     assert_parity(got, want)
+
+
+def _check_closest_hits(renderer, oracle, sc, rays):
+    idx, t = renderer.closest_hit(rays)
+    oi, ot = oracle.hit_scene_many(as_oracle_scene(sc), rays, threads=16)
+    assert np.array_equal(idx, oi)
+    hit = oi >= 0
+    assert np.array_equal(t[hit].view(np.uint32), ot[hit].view(np.uint32))
+    return hit.mean()
+
+
+def test_distance_cut_grazing_rays_in_the_dense_field(renderer, rt, oracle):
+    """Scenes scanned in place visit their batches near to far and let a ray's hit rule out the boxes that begin
+    farther along it.  Rays that skim the 40,004-sphere field just above the ground cross many batches, and their
+    first hit decides which of those are still scanned: index and t bits against the oracle's linear scan."""
+    sc = rt.random_scene(100)
+    renderer.upload(sc)
+    rng = np.random.default_rng(77)
+    n = 60000
+    A = np.stack([rng.uniform(-95, 95, n), rng.uniform(0.005, 0.45, n), rng.uniform(-95, 95, n)], 1)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    B = np.stack([np.cos(ang), rng.normal(0, 0.01, n), np.sin(ang)], 1) * rng.uniform(0.2, 5.0, (n, 1))
+    # a third of them start on a sphere's surface, as scattered rays do
+    k = rng.integers(1, len(sc), n // 3)
+    d = rng.normal(size=(n // 3, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    A[: n // 3] = sc["center"][k] + sc["radius"][k, None] * d
+    rays = np.concatenate([A, B], 1).astype(np.float32)
+    frac = _check_closest_hits(renderer, oracle, sc, rays)
+    assert frac > 0.8
+
+
+def test_distance_cut_overlapping_spheres_many_batches(renderer, rt, oracle):
+    """6,000 overlapping spheres of mixed size (scanned in place: 12 batches): origins inside spheres, far roots,
+    near-equal hit distances from spheres of different batches."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    sc = np.zeros(n, rt.SPHERE_DTYPE)
+    sc["center"] = np.stack([rng.uniform(-12, 12, n), rng.uniform(0, 3, n), rng.uniform(-12, 12, n)], 1)
+    sc["radius"] = rng.uniform(0.05, 0.7, n)
+    # pairs of spheres that meet a ray at almost the same distance: a copy moved by a few ulps
+    sc["center"][n // 2:] = sc["center"][: n // 2] + rng.normal(0, 3e-6, (n // 2, 3))
+    sc["radius"][n // 2:] = sc["radius"][: n // 2] * (1 + rng.normal(0, 2e-6, n // 2))
+    sc["albedo"] = 0.5
+    renderer.upload(sc)
+    m = 40000
+    A = np.stack([rng.uniform(-13, 13, m), rng.uniform(-0.5, 3.5, m), rng.uniform(-13, 13, m)], 1)
+    B = rng.normal(size=(m, 3)) * rng.uniform(0.1, 3.0, (m, 1))
+    rays = np.concatenate([A, B], 1).astype(np.float32)
+    frac = _check_closest_hits(renderer, oracle, sc, rays)
+    assert frac > 0.6
