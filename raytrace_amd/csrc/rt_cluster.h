@@ -46,6 +46,7 @@ namespace rtcluster {
 
 constexpr int kGroup = 8;                      // spheres per group = one chunk of the scan
 constexpr int kSuper = 4;                      // groups per super-group (a box of its own, tested first)
+constexpr int kRegionBatches = 8;              // batches per region (the level above the batches of a streamed scene)
 constexpr double kTinyRadius = 1.0 / 65536.0;   // radius below this: scanned by every ray (keeps sigma1 bounded)
 constexpr double kLargeFactor = 3.0;           // radius > this * median radius: scanned by every ray
 
@@ -54,6 +55,7 @@ struct Layout {
   std::vector<rtcore::GroupBox> boxes;  // one per group; h = +1e30 means "always scan", -1e30 "never"
   std::vector<rtcore::GroupBox> supers; // one per kSuper consecutive groups: the box around their boxes
   std::vector<rtcore::GroupBox> batches; // one per batch_spheres scan positions (an even number of them): the box around its super-groups
+  std::vector<rtcore::GroupBox> regions; // one per kRegionBatches batches (an even number of them): the box around their boxes
   std::vector<uint8_t> real_in_group; // real (non-pad) spheres per group
   uint32_t n_always_groups = 0;       // the first so many groups are the "always scan" ones; no box in `supers` covers them
   uint32_t n_scan = 0;                // = order.size(), a multiple of 2*kSuper*kGroup (a pair of super-groups)
@@ -212,6 +214,8 @@ inline Layout build_layout(const rt_sphere *s, size_t n, size_t batch_spheres) {
   for (size_t q0 = 0; q0 < L.supers.size(); q0 += supers_per_batch)
     L.batches.push_back(box_around(supers_or_always, q0, q0 + supers_per_batch, 0));
   if (L.batches.size() % 2) L.batches.push_back(rtcore::GroupBox{0.0f, 0.0f, 0.0f, -1.0e30f, -1.0e30f, -1.0e30f});
+  for (size_t b0 = 0; b0 < L.batches.size(); b0 += kRegionBatches) L.regions.push_back(box_around(L.batches, b0, b0 + kRegionBatches, 0));
+  if (L.regions.size() % 2) L.regions.push_back(rtcore::GroupBox{0.0f, 0.0f, 0.0f, -1.0e30f, -1.0e30f, -1.0e30f});
   L.n_scan = (uint32_t)L.order.size();
   if (h_min < 1e299) {   // (else there is nothing to cull)
     L.sigma0 = round_up_to_float(std::ldexp(1.0, -19) / h_min);

@@ -122,6 +122,9 @@ struct DeviceScene {
 // The boxes of the batches of a streamed scene follow the super-group boxes in the same array: 3 entries
 // per pair of batches (kBatchSpheres scan positions each), same layout.
 __device__ __host__ inline uint32_t batch_pairs(uint32_t n_pad) { return ((n_pad + kBatchSpheres - 1u) / kBatchSpheres + 1u) / 2u; }
+// ... and behind those the boxes of the regions (kRegionBatches = 8 batches each), again in pairs
+constexpr uint32_t kRegionBatches = 8;
+__device__ __host__ inline uint32_t region_pairs(uint32_t n_pad) { return ((2u * batch_pairs(n_pad) + kRegionBatches - 1u) / kRegionBatches + 1u) / 2u; }
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
@@ -878,23 +881,43 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
     if (kCull) {
       const uint32_t n_batch_pairs = batch_pairs(sc.n_pad);
       unsigned long long mine_lo = 0ull, mine_hi = 0ull;
-      BoxPairS cur = load_pair(0u);
-      for (uint32_t q = 0; q < n_batch_pairs; ++q) {
-        const BoxPairS nxt = load_pair(q + 1u < n_batch_pairs ? q + 1u : 0u);
-        bool pass[2];
-        box_pair_scalar(br, cur, pass);
-        const unsigned long long m0 = __ballot(pass[0]) & live_mask, m1 = __ballot(pass[1]) & live_mask;
-        const unsigned long long bits = (unsigned long long)((m0 != 0ull ? 1u : 0u) | (m1 != 0ull ? 2u : 0u));
+      uint32_t tested = 0;
+      if (all_mask == 0ull) {
+        // regions first (eight batches each, two boxes per packed evaluation), then the batch boxes of the regions
+        // some ray of the wave can touch; the boxes come through the scalar cache
+        const uint32_t n_region_pairs = region_pairs(sc.n_pad);
+        uint32_t regions = 0;
+        for (uint32_t q = 0; q < n_region_pairs; ++q) {
+          bool pass[2];
+          box_pair_scalar(br, load_pair(n_batch_pairs + q), pass);
+          const unsigned long long m0 = __ballot(pass[0]) & live_mask, m1 = __ballot(pass[1]) & live_mask;
+          regions |= ((m0 != 0ull ? 1u : 0u) | (m1 != 0ull ? 2u : 0u)) << (2u * q);
+        }
+        tested = 2u * n_region_pairs;
+        while (regions != 0u) {
+          const uint32_t r = (uint32_t)__builtin_ctz(regions);
+          regions &= regions - 1u;
+          const uint32_t q0 = r * (kRegionBatches / 2u), q1 = min(q0 + kRegionBatches / 2u, n_batch_pairs);
+          BoxPairS cur = load_pair(q0);
+          for (uint32_t q = q0; q < q1; ++q) {
+            const BoxPairS nxt = load_pair(q + 1u < q1 ? q + 1u : q0);
+            bool pass[2];
+            box_pair_scalar(br, cur, pass);
+            const unsigned long long m0 = __ballot(pass[0]) & live_mask, m1 = __ballot(pass[1]) & live_mask;
 #if RT_EXP == 39
-        h.fill[8] += (uint32_t)(__popcll(m0) + __popcll(m1));   // (lane, batch) pairs wanted
-        h.fill[9] += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);   // batches some lane wants
+            h.fill[8] += (uint32_t)(__popcll(m0) + __popcll(m1));   // (lane, batch) pairs wanted
+            h.fill[9] += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);   // batches some lane wants
 #endif
-        if (q < 32u) mine_lo |= bits << (2u * q);
-        else mine_hi |= bits << (2u * q - 64u);
-        cur = nxt;
+            const unsigned long long bits = (unsigned long long)((m0 != 0ull ? 1u : 0u) | (m1 != 0ull ? 2u : 0u));
+            if (q < 32u) mine_lo |= bits << (2u * q);
+            else mine_hi |= bits << (2u * q - 64u);
+            cur = nxt;
+          }
+          tested += 2u * (q1 - q0);
+        }
       }
       if (all_mask != 0ull) mine_lo = mine_hi = ~0ull;
-      h.box_tests += 2u * n_batch_pairs;
+      h.box_tests += tested;
       want_lo = mine_lo;
       want_hi = mine_hi;
     }
@@ -2419,7 +2442,17 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   }
   const uint32_t n_batch_pairs = (uint32_t)(L.batches.size() / 2);
   if (n_batch_pairs != batch_pairs(n_pad)) return fail(RT_ERR_LIMIT, "batch boxes do not match the scan length");
-  sboxes.resize(3 * (n_pad / 64) + 3 * n_batch_pairs);
+  const uint32_t n_region_pairs = (uint32_t)(L.regions.size() / 2);
+  static_assert(kRegionBatches == (uint32_t)rtcluster::kRegionBatches, "one region size");
+  if (n_region_pairs != region_pairs(n_pad)) return fail(RT_ERR_LIMIT, "region boxes do not match the scan length");
+  sboxes.resize(3 * (n_pad / 64) + 3 * n_batch_pairs + 3 * n_region_pairs);
+  for (uint32_t q = 0; q < n_region_pairs; ++q) {
+    const GroupBox &b0 = L.regions[2 * q], &b1 = L.regions[2 * q + 1];
+    float4 *dst = &sboxes[3 * (n_pad / 64) + 3 * n_batch_pairs + 3 * q];
+    dst[0] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
+    dst[1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
+    dst[2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
+  }
   for (uint32_t q = 0; q < n_batch_pairs; ++q) {
     const GroupBox &b0 = L.batches[2 * q], &b1 = L.batches[2 * q + 1];
     float4 *dst = &sboxes[3 * (n_pad / 64) + 3 * q];
