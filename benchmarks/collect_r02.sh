@@ -22,4 +22,9 @@ done
 timeout -k 10 200 python3 benchmarks/phase_profile.py --spp 64 > "$out/phase_profile.jsonl" 2> /dev/null
 timeout -k 10 300 python3 benchmarks/stage_profile.py > "$out/stage_profile.jsonl" 2> /dev/null
 timeout -k 10 100 python3 benchmarks/tail_probe.py > "$out/tail_probe.txt" 2> /dev/null
+if [ -f _out/exp/lib_exp39.so ]; then
+  for w in final1080 glass1080 dense1080; do
+    RT_AMD_DEVICE_LIB=$PWD/_out/exp/lib_exp39.so timeout -k 10 120 python3 benchmarks/fill_profile.py --workload $w > "$out/thread_efficiency_by_part_$w.json" 2> /dev/null
+  done
+fi
 echo collected
