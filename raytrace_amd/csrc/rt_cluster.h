@@ -46,6 +46,7 @@ namespace rtcluster {
 
 constexpr int kGroup = 8;                      // spheres per group = one chunk of the scan
 constexpr int kSuper = 4;                      // groups per super-group (a box of its own, tested first)
+constexpr int kQuarterSupers = 4;               // super-groups per quarter (128 scan positions: the level between super-group and batch)
 constexpr int kRegionBatches = 8;              // batches per region (the level above the batches of a streamed scene)
 constexpr double kTinyRadius = 1.0 / 65536.0;   // radius below this: scanned by every ray (keeps sigma1 bounded)
 constexpr double kLargeFactor = 3.0;           // radius > this * median radius: scanned by every ray
@@ -55,6 +56,7 @@ struct Layout {
   std::vector<rtcore::GroupBox> boxes;  // one per group; h = +1e30 means "always scan", -1e30 "never"
   std::vector<rtcore::GroupBox> supers; // one per kSuper consecutive groups: the box around their boxes
   std::vector<rtcore::GroupBox> batches; // one per batch_spheres scan positions (an even number of them): the box around its super-groups
+  std::vector<rtcore::GroupBox> quarters; // one per kQuarterSupers super-groups (an even number of them): the box around their boxes
   std::vector<rtcore::GroupBox> regions; // one per kRegionBatches batches (an even number of them): the box around their boxes
   std::vector<uint8_t> real_in_group; // real (non-pad) spheres per group
   uint32_t n_always_groups = 0;       // the first so many groups are the "always scan" ones; no box in `supers` covers them
@@ -210,6 +212,8 @@ inline Layout build_layout(const rt_sphere *s, size_t n, size_t batch_spheres) {
     L.supers.push_back(box_around(L.boxes, g0, g0 + kSuper, L.n_always_groups));
     supers_or_always.push_back(box_around(L.boxes, g0, g0 + kSuper, 0));
   }
+  for (size_t q0 = 0; q0 < L.supers.size(); q0 += kQuarterSupers) L.quarters.push_back(box_around(L.supers, q0, q0 + kQuarterSupers, 0));
+  if (L.quarters.size() % 2) L.quarters.push_back(rtcore::GroupBox{0.0f, 0.0f, 0.0f, -1.0e30f, -1.0e30f, -1.0e30f});
   const size_t supers_per_batch = batch_spheres / (kSuper * kGroup);
   for (size_t q0 = 0; q0 < L.supers.size(); q0 += supers_per_batch)
     L.batches.push_back(box_around(supers_or_always, q0, q0 + supers_per_batch, 0));

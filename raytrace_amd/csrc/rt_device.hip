@@ -99,6 +99,7 @@ struct DeviceScene {
   const float4 *filter;   // n_pad entries, sphere pairs {cx0,cx1,cy0,cy1},{cz0,cz1,K'0,K'1}; pads never pass
   const float4 *boxes;    // 3 entries per round of two groups: {cx0,cx1,cy0,cy1},{cz0,cz1,hx0,hx1},{hy0,hy1,hz0,hz1}
   const float4 *sboxes;   // 3 entries per pair of super-groups (64 spheres), same layout as boxes; then the batch boxes
+  const float4 *qboxes;   // 3 entries per pair of quarters (256 spheres: a quarter is four super-groups), same layout
   const float4 *exact;    // n_pad entries {cx, cy, cz, r*r}
   const uint32_t *orig;   // n_pad entries: index in the caller's list (ties go to the lowest), ~0 for pads
   // for shading, in the CALLER's order (n entries):
@@ -122,6 +123,8 @@ struct DeviceScene {
 // The boxes of the batches of a streamed scene follow the super-group boxes in the same array: 3 entries
 // per pair of batches (kBatchSpheres scan positions each), same layout.
 __device__ __host__ inline uint32_t batch_pairs(uint32_t n_pad) { return ((n_pad + kBatchSpheres - 1u) / kBatchSpheres + 1u) / 2u; }
+// pairs of quarters (a quarter = four super-groups = 128 scan positions) in `entries` scan positions
+__device__ __host__ inline uint32_t quarter_pairs(uint32_t entries) { return (entries + 255u) / 256u; }
 // ... and behind those the boxes of the regions (kRegionBatches = 8 batches each), again in pairs
 constexpr uint32_t kRegionBatches = 8;
 __device__ __host__ inline uint32_t region_pairs(uint32_t n_pad) { return ((2u * batch_pairs(n_pad) + kRegionBatches - 1u) / kRegionBatches + 1u) / 2u; }
@@ -198,20 +201,21 @@ constexpr uint32_t kWaveListCapFull = 768, kWaveListCapCull = 320;
 constexpr uint32_t wave_list_cap(bool cull) { return cull ? kWaveListCapCull : kWaveListCapFull; }
 constexpr uint32_t kWaveListFlushFull = kWaveListCapFull - 64u * kChunk;   // drain above this before a chunk
 static_assert(kWaveListCapFull >= 64u * kChunk && kWaveListCapCull >= 32u * kChunk, "list too short");
-constexpr uint32_t kPairListCap = 288;              // (lane, group) entries per wave, 16 bits each (with this the
-                                                    // workgroup's LDS is 31,936 bytes: five fit a CU's 160 KiB in 1280-byte units)
+constexpr uint32_t kPairListCap = 280;              // (lane, group) entries per wave, 16 bits each (with this the
+                                                    // workgroup's LDS is 31,968 bytes for a 512-position scene: five fit
+                                                    // a CU's 160 KiB, which is handed out in 1280-byte units)
 constexpr uint32_t kPairListFlush = kPairListCap - 2u * 64u;       // a round adds at most two groups for 64 lanes
 
 struct ScanLds {
   float4 *pairs;
   float4 *boxes;                 // 3 per round (16 spheres)
   float4 *sboxes;                // 3 per pair of super-groups (64 spheres)
+  float4 *qboxes;                // 3 per pair of quarters (256 spheres)
   float4 *rays;                  // 3 per lane: {A, a}, {B, -(B.B) of the filter}, {1/a as a double, A.B, naaa of the filter}
   unsigned long long *best;      // 1 per lane
   uint32_t *wlist;               // wave_list_cap() per wave: (owner lane << 16) | scan position
   uint16_t *plist;               // kPairListCap per wave: (group within the batch << 6) | owner lane
   uint8_t *real8;                // per group of the batch: its real (non-pad) spheres
-  unsigned long long *bmask;     // 2 per wave: the batches the wave's rays can touch (streamed scenes)
 };
 
 template <bool kCull>
@@ -220,12 +224,12 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
   l.pairs = reinterpret_cast<float4 *>(smem);
   l.boxes = l.pairs + entries;
   l.sboxes = l.boxes + 3u * (entries / 16u);
-  l.rays = l.sboxes + 3u * (entries / 64u);
+  l.qboxes = l.sboxes + 3u * (entries / 64u);
+  l.rays = l.qboxes + 3u * quarter_pairs(entries);
   l.best = reinterpret_cast<unsigned long long *>(l.rays + 3 * kBlockThreads);
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
   l.plist = reinterpret_cast<uint16_t *>(l.wlist + (kBlockThreads / 64) * wave_list_cap(kCull));
   l.real8 = reinterpret_cast<uint8_t *>(l.plist + (kBlockThreads / 64) * kPairListCap);
-  l.bmask = reinterpret_cast<unsigned long long *>(l.real8 + ((entries / 8u + 15u) & ~15u));
   return l;
 }
 
@@ -234,6 +238,7 @@ __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds
   for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[i] = sc.filter[base + i];
   for (uint32_t i = tid; i < 3u * (count / 16u); i += kBlockThreads) lds.boxes[i] = sc.boxes[3u * (base / 16u) + i];
   for (uint32_t i = tid; i < 3u * (count / 64u); i += kBlockThreads) lds.sboxes[i] = sc.sboxes[3u * (base / 64u) + i];
+  for (uint32_t i = tid; i < 3u * quarter_pairs(count); i += kBlockThreads) lds.qboxes[i] = sc.qboxes[3u * (base / 256u) + i];
   for (uint32_t i = tid; i < count / 8u; i += kBlockThreads) lds.real8[i] = sc.group_real[base / 8u + i];
 }
 
@@ -747,20 +752,47 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
       touched |= (s0 != 0ull ? bit : 0ull) | (s1 != 0ull ? bit << 1 : 0ull);
     };
     const uint32_t n_pairs = count / kPairSpan;
-    float4 sa[3] = {lds_sboxes[0], lds_sboxes[1], lds_sboxes[2]}, sb[3];
-    for (uint32_t pi = 0; pi < n_pairs; pi += 2u) {
-      const uint32_t ib = 3u * (pi + 1u < n_pairs ? pi + 1u : 0u);   // (a read past the end is redirected and not used)
-      sb[0] = lds_sboxes[ib];
-      sb[1] = lds_sboxes[ib + 1];
-      sb[2] = lds_sboxes[ib + 2];
-      test_pair(sa, pi);
-      const uint32_t ia = 3u * (pi + 2u < n_pairs ? pi + 2u : 0u);
-      sa[0] = lds_sboxes[ia];
-      sa[1] = lds_sboxes[ia + 1];
-      sa[2] = lds_sboxes[ia + 2];
-      if (pi + 1u < n_pairs) test_pair(sb, pi + 1u);
+    if (n_pairs > 4u) {
+      // more than four pairs of super-groups: the quarters first (four super-groups each, two boxes per packed
+      // evaluation), then the two pairs of super-groups of every quarter some ray of the wave can touch
+      const float4 *lds_qboxes = lds.qboxes;
+      const uint32_t n_qpairs = quarter_pairs(count);
+      uint32_t quarters = 0u;
+      for (uint32_t qp = 0; qp < n_qpairs; ++qp) {
+        const float4 qq[3] = {lds_qboxes[3u * qp], lds_qboxes[3u * qp + 1u], lds_qboxes[3u * qp + 2u]};
+        bool qpass[2];
+        box_pair<kCut>(br, qq, qpass, cut);
+        const unsigned long long s0 = (__ballot(qpass[0]) & live_mask) | all_mask, s1 = (__ballot(qpass[1]) & live_mask) | all_mask;
+        quarters |= ((s0 != 0ull ? 1u : 0u) | (s1 != 0ull ? 2u : 0u)) << (2u * qp);
+      }
+      tests += 2u * n_qpairs;
+      while (quarters != 0u) {
+        const uint32_t p0 = 2u * (uint32_t)__builtin_ctz(quarters);
+        quarters &= quarters - 1u;
+        const bool two = p0 + 1u < n_pairs;
+        const uint32_t i0 = 3u * p0, i1 = 3u * (two ? p0 + 1u : p0);
+        const float4 sa[3] = {lds_sboxes[i0], lds_sboxes[i0 + 1u], lds_sboxes[i0 + 2u]};
+        const float4 sb[3] = {lds_sboxes[i1], lds_sboxes[i1 + 1u], lds_sboxes[i1 + 2u]};
+        test_pair(sa, p0);
+        if (two) test_pair(sb, p0 + 1u);
+        tests += two ? 4u : 2u;
+      }
+    } else {
+      float4 sa[3] = {lds_sboxes[0], lds_sboxes[1], lds_sboxes[2]}, sb[3];
+      for (uint32_t pi = 0; pi < n_pairs; pi += 2u) {
+        const uint32_t ib = 3u * (pi + 1u < n_pairs ? pi + 1u : 0u);   // (a read past the end is redirected and not used)
+        sb[0] = lds_sboxes[ib];
+        sb[1] = lds_sboxes[ib + 1];
+        sb[2] = lds_sboxes[ib + 2];
+        test_pair(sa, pi);
+        const uint32_t ia = 3u * (pi + 2u < n_pairs ? pi + 2u : 0u);
+        sa[0] = lds_sboxes[ia];
+        sa[1] = lds_sboxes[ia + 1];
+        sa[2] = lds_sboxes[ia + 2];
+        if (pi + 1u < n_pairs) test_pair(sb, pi + 1u);
+      }
+      tests += 2u * n_pairs;
     }
-    tests += 2u * n_pairs;
   }
   RT_HSTAGE_END(36);
   RT_HSTAGE_BEGIN(37);
@@ -930,6 +962,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       in_place.pairs = const_cast<float4 *>(sc.filter + base);
       in_place.boxes = const_cast<float4 *>(sc.boxes + 3u * (base / 16u));
       in_place.sboxes = const_cast<float4 *>(sc.sboxes + 3u * (base / 64u));
+      in_place.qboxes = const_cast<float4 *>(sc.qboxes + 3u * (base / 256u));
       in_place.real8 = const_cast<uint8_t *>(sc.group_real + base / 8u);
       scan_batch<kCull, kCull>(sc, in_place, base, span, fr, br, alive, uncullable, w, h, cut);
     };
@@ -1924,7 +1957,7 @@ struct rt_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events[kHistory];
   int trace_used[kHistory] = {};
   long renders = 0;
-  DevBuf<float4> filter, boxes, sboxes, exact, geom_o, mat_o, shade_o;
+  DevBuf<float4> filter, boxes, sboxes, qboxes, exact, geom_o, mat_o, shade_o;
   DevBuf<int32_t> type_o;
   DevBuf<uint32_t> orig;
   DevBuf<double> inv_r_o;
@@ -1967,15 +2000,14 @@ int check_job(const rt_job *job) {
 }
 
 DeviceScene scene_view(const rt_ctx *c) {
-  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->shade_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->cut_reach, c->cut_b, c->n_full, c->n_always_groups};
+  return DeviceScene{c->filter.p, c->boxes.p, c->sboxes.p, c->qboxes.p, c->exact.p, c->orig.p, c->geom_o.p, c->mat_o.p, c->type_o.p, c->inv_r_o.p, c->shade_o.p, c->group_real.p, c->n, c->n_pad, c->sigma0, c->sigma1, c->cut_reach, c->cut_b, c->n_full, c->n_always_groups};
 }
 
 size_t scan_lds_bytes(uint32_t entries, bool cull) {
-  return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u) * sizeof(float4) +  // pair image, boxes
+  return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u + quarter_pairs(entries)) * sizeof(float4) +  // pair image, boxes
          (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
          (size_t)(kBlockThreads / 64) * (wave_list_cap(cull) * sizeof(uint32_t) + kPairListCap * sizeof(uint16_t)) +  // wave lists
-         (size_t)((entries / 8u + 15u) & ~15u) +                                            // real spheres per group
-         (size_t)(kBlockThreads / 64) * 2 * sizeof(unsigned long long);                      // batch masks
+         (size_t)((entries / 8u + 15u) & ~15u);                                             // real spheres per group
 }
 size_t trace_lds_bytes(uint32_t n_pad, bool cull) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : 0u, cull); }
 
@@ -2310,6 +2342,7 @@ int rt_ctx_destroy(rt_ctx *c) {
   c->filter.release();
   c->boxes.release();
   c->sboxes.release();
+  c->qboxes.release();
   c->orig.release();
   c->inv_r_o.release();
   c->shade_o.release();
@@ -2440,6 +2473,14 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     sboxes[3 * q + 1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
     sboxes[3 * q + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
   }
+  std::vector<float4> qboxes(3 * quarter_pairs(n_pad));
+  if (L.quarters.size() != 2 * (size_t)quarter_pairs(n_pad)) return fail(RT_ERR_LIMIT, "quarter boxes do not match the scan length");
+  for (uint32_t q = 0; q < quarter_pairs(n_pad); ++q) {
+    const GroupBox &b0 = L.quarters[2 * q], &b1 = L.quarters[2 * q + 1];
+    qboxes[3 * q] = make_float4(b0.cx, b1.cx, b0.cy, b1.cy);
+    qboxes[3 * q + 1] = make_float4(b0.cz, b1.cz, b0.hx, b1.hx);
+    qboxes[3 * q + 2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
+  }
   const uint32_t n_batch_pairs = (uint32_t)(L.batches.size() / 2);
   if (n_batch_pairs != batch_pairs(n_pad)) return fail(RT_ERR_LIMIT, "batch boxes do not match the scan length");
   const uint32_t n_region_pairs = (uint32_t)(L.regions.size() / 2);
@@ -2461,7 +2502,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
     dst[2] = make_float4(b0.hy, b1.hy, b0.hz, b1.hz);
   }
   int rc;
-  if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(sboxes.size())) || (rc = c->exact.reserve(n_pad)) ||
+  if ((rc = c->filter.reserve(n_pad)) || (rc = c->boxes.reserve(3 * (n_pad / 16))) || (rc = c->sboxes.reserve(sboxes.size())) || (rc = c->qboxes.reserve(qboxes.size())) || (rc = c->exact.reserve(n_pad)) ||
       (rc = c->geom_o.reserve(n)) || (rc = c->mat_o.reserve(n)) || (rc = c->type_o.reserve(n)) ||
       (rc = c->orig.reserve(n_pad)) || (rc = c->inv_r_o.reserve(n)) || (rc = c->shade_o.reserve(3 * n)) || (rc = c->group_real.reserve(n_pad / 8)))
     return rc;
@@ -2469,6 +2510,7 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   RT_HIP(hipMemcpy(c->filter.p, filter.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->boxes.p, boxes.data(), 3 * (n_pad / 16) * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->sboxes.p, sboxes.data(), sboxes.size() * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(c->qboxes.p, qboxes.data(), qboxes.size() * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->exact.p, exact.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->geom_o.p, geom_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(c->mat_o.p, mat_o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
