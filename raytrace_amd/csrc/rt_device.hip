@@ -766,6 +766,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
         quarters |= ((s0 != 0ull ? 1u : 0u) | (s1 != 0ull ? 2u : 0u)) << (2u * qp);
       }
       tests += 2u * n_qpairs;
+      quarters &= (1u << ((n_pairs + 1u) / 2u)) - 1u;   // (rays outside the boxes' range set every bit: not the padding's)
       while (quarters != 0u) {
         const uint32_t p0 = 2u * (uint32_t)__builtin_ctz(quarters);
         quarters &= quarters - 1u;

@@ -164,3 +164,21 @@ def test_distance_cut_overlapping_spheres_many_batches(renderer, rt, oracle):
     rays = np.concatenate([A, B], 1).astype(np.float32)
     frac = _check_closest_hits(renderer, oracle, sc, rays)
     assert frac > 0.6
+
+
+@pytest.mark.parametrize("n", [513, 1100, 2040])
+def test_rays_outside_the_box_range_in_scenes_with_padded_quarters(renderer, rt, oracle, n):
+    """Rays whose direction is too long for the box arithmetic (|B|^2 >= 2^40: a camera focused two million units
+    away) are not culled: they list every group.  In a scene whose scan length is not a multiple of 256 the last
+    quarter box is padding, and 'every' must not include it."""
+    full = rt.random_scene(30)
+    rng = np.random.default_rng(n)
+    sc = full[np.sort(rng.choice(len(full), size=n, replace=False))].copy()
+    renderer.upload(sc)
+    nx, ny, spp = 64, 36, 2
+    cam = rt.camera_new((10, 2.5, 5), (-4, 0, -2), (0, 1, 0), 20.0, nx / ny, 0.0, 2.0e6)
+    got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=3))
+    want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=3, host_threads=16)
+    assert np.array_equal(got["rgb8"], want["rgb8"])
+    assert np.array_equal(got["linear"].view(np.uint32), want["linear"].view(np.uint32))
+    assert np.array_equal(got["first_hit"], want["first_hit"])
