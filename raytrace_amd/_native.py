@@ -124,6 +124,7 @@ HOST_SYMBOLS = {
     "rth_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "rth_write_ppm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "rth_write_png": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "rth_write_jpg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
     "rth_raytrace": (C.c_int, [C.POINTER(RtCamera), C.c_void_p, C.c_size_t, C.POINTER(RthRenderOpts), C.c_void_p,
                                C.POINTER(C.c_float)]),
     "rth_raytrace_ex": (C.c_int, [C.POINTER(RtCamera), C.c_void_p, C.c_size_t, C.POINTER(RthRenderOpts), C.c_void_p,

@@ -47,7 +47,7 @@ def build_device(force=False):
 
 def build_host(force=False):
     hdir = os.path.join(PKG, "host")
-    srcs = [os.path.join(hdir, f) for f in ("scene.c", "driver.c", "service.c")]
+    srcs = [os.path.join(hdir, f) for f in ("scene.c", "driver.c", "service.c", "jpeg.c")]
     deps = srcs + [os.path.join(hdir, "rt_host.h"), os.path.join(ROOT, "include", "rt_amd.h")]
     out = os.path.join(LIB, "libraytrace_host.so")
     dev = build_device(force)

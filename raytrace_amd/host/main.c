@@ -2,7 +2,7 @@
  * main.c -- command-line renderer: the reference's CLI (c/main.c:32-138) in
  * front of the GPU path.  Same options with the same meaning and messages
  * where they still apply:
- *     -o <file>.<ppm|png> | -   output file; '-' writes the PPM to stdout
+ *     -o <file>.<ppm|png|jpg> | -   output file; '-' writes the PPM to stdout
  *     -n <samples>          samples per pixel (default 10, c/main.c:61)
  *     -t <devices>          number of GPUs to shard over (the reference's
  *                           thread count, c/main.c:62; default 1)
@@ -12,9 +12,9 @@
  *     -d <max depth>  -S <seed>
  *     -i <scene file>       render a scene dump (rth_scene_load) instead of a built-in scene
  *     -D <scene file>       also write the scene that is rendered as a scene dump
- * PPM and PNG are written (the PNG by the host library's own stored-deflate
- * encoder); JPG in the reference comes from a vendored third-party encoder
- * and is outside this path.
+ * PPM, PNG and JPG (quality 90, c/main.c:434) are written by the host library's
+ * own encoders: conforming files of the same picture, not the bytes of the
+ * reference's vendored third-party encoders.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,7 +31,7 @@ static void usage(void) {
   fprintf(stderr,
           "Usage: %s [-n <number of samples>] [-t <number of GPUs>] [-x <width>] [-y <height>]\n"
           "          [-s small|final|dense|glass|trivial | -i <scene file>] [-D <scene file>] [-d <max depth>] [-S <seed>]\n"
-          "          -o <output file>.<ppm/png>\n"
+          "          -o <output file>.<ppm/png/jpg>\n"
           "\n"
           "If <output file> is '-' then a ppm image is written on stdout.\n"
           "\n"
@@ -39,6 +39,7 @@ static void usage(void) {
           "\n",
           argv0);
   fprintf(stderr, "	%s -n 100 -t 8 -s final -x 1920 -y 1080 -o out.ppm\n", argv0);
+  fprintf(stderr, "	%s -n 100 -t 4 -o out.jpg\n", argv0);
   fprintf(stderr, "	%s -o out.ppm\n", argv0);
   fprintf(stderr, "	%s -o - > out.ppm\n", argv0);
   exit(1);
@@ -57,7 +58,7 @@ static long positive(const char *what, const char *arg) {
 int main(int argc, char **argv) {
   argv0 = argv[0];
   FILE *fp = NULL;
-  int write_png = 0;
+  int write_png = 0, write_jpg = 0;
   rth_render_opts o;
   memset(&o, 0, sizeof o);
   o.nx = 600; o.ny = 300;          /* c/main.c:486 */
@@ -74,12 +75,14 @@ int main(int argc, char **argv) {
       if (strcmp(optarg, "-") == 0) { fp = stdout; break; }
       const char *ext = strrchr(optarg, '.');
       if (ext == NULL) {
-        fprintf(stderr, "missing file name extension, support ppm/png\n");   /* c/main.c:80-83 */
+        fprintf(stderr, "missing file name extension, support ppm/png/jpg\n");   /* c/main.c:73-77 */
         usage();
       } else if (strcasecmp(ext, ".png") == 0) {
         write_png = 1;
+      } else if (strcasecmp(ext, ".jpg") == 0 || strcasecmp(ext, ".jpeg") == 0) {   /* c/main.c:80-81 */
+        write_jpg = 1;
       } else if (strcasecmp(ext, ".ppm") != 0) {
-        fprintf(stderr, "unsupported file extension: %s (only support ppm/png)\n", ext);
+        fprintf(stderr, "unsupported file extension: %s (only support ppm/png/jpg)\n", ext);
         usage();
       }
       fp = fopen(optarg, "wb");
@@ -133,7 +136,7 @@ int main(int argc, char **argv) {
   double paths = (double)o.nx * o.ny * o.nsamples;
   fprintf(stderr, "raytracing took %.3f seconds (%zu spheres, %ux%u, %u spp, %d rank(s) on %d GPU(s); kernels %.3f ms, %.3g paths/s)\n",
           wall, n, o.nx, o.ny, o.nsamples, o.n_devices, devices_used, kernel_ms, kernel_ms > 0 ? paths / (kernel_ms * 1e-3) : 0.0);
-  if ((write_png ? rth_write_png(fp, img, o.nx, o.ny) : rth_write_ppm(fp, img, o.nx, o.ny)) != RT_OK) {
+  if ((write_png ? rth_write_png(fp, img, o.nx, o.ny) : write_jpg ? rth_write_jpg(fp, img, o.nx, o.ny, 90) : rth_write_ppm(fp, img, o.nx, o.ny)) != RT_OK) {
     perror("could not write image");
     return 1;
   }

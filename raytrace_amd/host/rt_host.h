@@ -55,6 +55,10 @@ int rth_scene_load(const char *path, rt_sphere **out, size_t *n);
 int rth_write_ppm(FILE *fp, const uint8_t *rgb8, size_t w, size_t h);
 /* c/main.c:427-433: 8-bit RGB PNG (stored, i.e. uncompressed, deflate blocks) */
 int rth_write_png(FILE *fp, const uint8_t *rgb8, size_t w, size_t h);
+/* c/main.c:430-435: baseline JPEG (JFIF, Y Cb Cr 4:4:4, the standard's example tables scaled for `quality` 1..100;
+ * the reference passes 90).  The build's own encoder: a conforming file of the same picture, not the bytes of the
+ * reference's third-party encoder. */
+int rth_write_jpg(FILE *fp, const uint8_t *rgb8, size_t w, size_t h, int quality);
 
 /* raytrace(), c/main.c:485-548, with GPUs in place of threads: row tiles of
  * tile_rows rows are dealt round-robin over n_devices contexts (one host

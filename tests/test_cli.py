@@ -89,3 +89,21 @@ def test_cli_renders_a_scene_dump(tmp_path, rt, oracle):
     want = oracle.render_det(rt.camera_default(160, 90).as_array(), as_oracle_scene(sc), 160, 90, 3, seed=0, host_threads=16,
                              want_debug=False)["rgb8"]
     assert p.stdout == b"P6\n160 90 255\n" + want.tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_writes_a_jpeg_of_the_oracles_picture(tmp_path, rt, oracle):
+    """.jpg / .jpeg pick the JPEG writer at quality 90 (c/main.c:80-81, 434); decoded by Pillow the picture is the
+    oracle's to within what quality 90 loses."""
+    from PIL import Image
+    out = tmp_path / "o.jpeg"
+    p = run("-s", "final", "-x", "200", "-y", "100", "-n", "4", "-o", str(out))
+    assert p.returncode == 0, p.stderr
+    from conftest import as_oracle_scene
+    want = oracle.render_det(rt.camera_default(200, 100).as_array(), as_oracle_scene(rt.random_scene()), 200, 100, 4, seed=0,
+                             host_threads=16, want_debug=False)["rgb8"]
+    with Image.open(str(out)) as im:
+        assert im.format == "JPEG" and im.size == (200, 100)
+        back = np.asarray(im.convert("RGB"), np.float64)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((back - want.astype(np.float64)) ** 2))
+    assert psnr > 30.0, psnr       # (4 spp: the picture is noisy, which costs a JPEG more than a smooth one)

@@ -136,3 +136,67 @@ def test_png_writer_produces_a_decodable_image(rt, tmp_path):
         rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 3 * w + 1)
         assert (rows[:, 0] == 0).all()
         assert np.array_equal(rows[:, 1:].reshape(h, w, 3), img)
+
+
+def _fopen(path):
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    fp = libc.fopen(path.encode(), b"wb")
+    assert fp
+    return libc, fp
+
+
+def test_jpeg_writer_is_decoded_by_an_independent_decoder(rt, tmp_path):
+    """rth_write_jpg (c/main.c:430-435 writes JPG at quality 90 through a third-party encoder; this one is the
+    build's own): Pillow decodes the file to the source's size and, at quality 90, to within 36 dB of a smooth
+    picture with detail in it; a flat picture comes back flat; quality orders the file sizes; the Huffman
+    tables written are complete prefix codes."""
+    from PIL import Image
+    yy, xx = np.mgrid[0:200, 0:300]
+    rng = np.random.default_rng(4)
+    smooth = np.stack([127 + 120 * np.sin(xx / 23.0) * np.cos(yy / 31.0), xx * 255.0 / 299, 255 - yy * 255.0 / 199], -1)
+    smooth[60:140, 100:200] += rng.normal(0, 12, (80, 100, 3))                 # some texture
+    pictures = {"smooth": np.clip(smooth, 0, 255).astype(np.uint8), "flat": np.full((5, 37, 3), (200, 30, 90), np.uint8),
+                "one": np.array([[[255, 255, 255]]], np.uint8), "edge": rng.integers(0, 256, (9, 17, 3), dtype=np.uint8)}
+    sizes = {}
+    for name, img in pictures.items():
+        h, w = img.shape[:2]
+        for q in (90, 50) if name == "smooth" else (90,):
+            path = str(tmp_path / f"{name}_{q}.jpg")
+            libc, fp = _fopen(path)
+            assert rt._native.host.rth_write_jpg(fp, np.ascontiguousarray(img).ctypes.data, w, h, q) == 0
+            libc.fclose(fp)
+            raw = open(path, "rb").read()
+            assert raw[:4] == b"\xff\xd8\xff\xe0" and raw[6:11] == b"JFIF\x00" and raw[-2:] == b"\xff\xd9"
+            with Image.open(path) as im:
+                assert im.format == "JPEG" and im.size == (w, h) and im.mode == "RGB"
+                back = np.asarray(im.convert("RGB"), np.float64)
+            err = np.mean((back - img.astype(np.float64)) ** 2)
+            psnr = 99.0 if err == 0 else 10 * np.log10(255.0 ** 2 / err)
+            sizes[(name, q)] = len(raw)
+            if name == "smooth":
+                assert psnr > (36.0 if q == 90 else 30.0), (q, psnr)
+            elif name in ("flat", "one"):
+                assert np.abs(back - img).max() <= 2, name
+            else:
+                assert psnr > 20.0                                                # noise at 4:4:4, quality 90
+    assert sizes[("smooth", 50)] < sizes[("smooth", 90)] < 3 * 200 * 300
+    # the tables as written: every DHT segment is a complete code (Kraft sum 1 less the reserved all-ones code)
+    raw = open(str(tmp_path / "smooth_90.jpg"), "rb").read()
+    pos, seen = 2, 0
+    while raw[pos + 1] != 0xDA:
+        n = (raw[pos + 2] << 8) | raw[pos + 3]
+        if raw[pos + 1] == 0xC4:
+            bits = raw[pos + 5:pos + 21]
+            vals = raw[pos + 21:pos + 2 + n]
+            assert len(vals) == sum(bits) == len(set(vals))
+            assert sum(b * 2.0 ** -(i + 1) for i, b in enumerate(bits)) <= 1.0 - 2.0 ** -16
+            seen += 1
+        pos += 2 + n
+    assert seen == 4
+
+
+def test_jpeg_writer_rejects_bad_arguments(rt):
+    assert rt._native.host.rth_write_jpg(None, None, 1, 1, 90) == 1
