@@ -6,8 +6,9 @@
 // "first root inside (tmin, FLT_MAX)" over all spheres, and among equal t the
 // lowest index wins (strict `<`, c/main.c:225, 249-251).  The kernels
 // therefore scan in an order of their own -- large spheres first, the rest
-// split recursively at the median into groups of kGroup neighbours -- and
-// break ties by the original index.
+// split recursively along the longest axis into groups of kGroup neighbours,
+// every split at an aligned group boundary so that aligned runs of groups are
+// compact regions -- and break ties by the original index.
 //
 // Each group of regular spheres has an axis-aligned box; a ray that misses the
 // box on its half line t >= 0 skips the group (test and proof obligations in
@@ -21,11 +22,12 @@
 // |A|^2 on the half extents; this file computes sigma0 and sigma1.  Four
 // consecutive groups form a super-group whose box (the box around the four,
 // widened once more for its own slab arithmetic) is tested first; a wave skips
-// the four box tests of a super-group no lane's ray can touch.  Scenes too
-// large to stay in LDS are scanned in batches of `batch_spheres` consecutive
-// scan positions; each batch has a box of its own (around its super-group
-// boxes, widened the same way), and a workgroup skips the batches none of its
-// rays can touch.
+// the four box tests of a super-group no lane's ray can touch.  Above the
+// super-groups the same again: four of them form a quarter, and in scenes too
+// large to stay in LDS, which are scanned in batches of `batch_spheres`
+// consecutive scan positions, each batch and each region of eight batches has
+// a box (around the boxes below it, widened the same way); a wave skips what
+// none of its rays can touch.
 //
 // Scenes like the reference's are flat fields of small spheres on one huge
 // one; boxes around neighbours are flat too, so most rays that fly over a

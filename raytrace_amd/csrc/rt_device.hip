@@ -897,9 +897,10 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   if (kBatched) {
     // A scene too large for LDS is scanned where it lies: its pair image, boxes and group sizes are read from
     // global memory (the 16 bytes per sphere of even a 65,535-sphere scene stay in the L2 of every XCD), batch
-    // by batch -- a batch is kBatchSpheres scan positions with a box of its own.  Which batches: those whose
-    // box some ray of the WAVE can touch.  Every lane tests its ray against every batch box (two per packed
-    // evaluation, the boxes read through the scalar cache one pair ahead).  Nothing is shared between the
+    // by batch -- a batch is kBatchSpheres scan positions with a box of its own, eight batches a region with a
+    // box above those.  Which batches: those whose box some ray of the WAVE can touch, found by every lane
+    // testing its ray against the region boxes and then against the batch boxes of the regions that are
+    // touched (two boxes per packed evaluation, read through the scalar cache).  Nothing is shared between the
     // waves of the workgroup, so there is no barrier in the scan and a wave visits only what its own 64 rays
     // need.  (Staging each batch into LDS for the whole workgroup, two barriers per batch, left the vector
     // ALUs idle 60 % of the time.)
