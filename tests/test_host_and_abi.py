@@ -200,3 +200,22 @@ def test_jpeg_writer_is_decoded_by_an_independent_decoder(rt, tmp_path):
 
 def test_jpeg_writer_rejects_bad_arguments(rt):
     assert rt._native.host.rth_write_jpg(None, None, 1, 1, 90) == 1
+
+
+def test_host_code_under_address_and_undefined_sanitizers(tmp_path):
+    """The host library's CPU-only code built with -fsanitize=address,undefined and run through its builders, writers,
+    scene dumps and argument errors (tests/support/host_sanitize.c)."""
+    import subprocess
+    host = os.path.join(ROOT, "raytrace_amd", "host")
+    exe = str(tmp_path / "host_sanitize")
+    srcs = [os.path.join(ROOT, "tests", "support", "host_sanitize.c")] + [os.path.join(host, f) for f in ("scene.c", "driver.c", "service.c", "jpeg.c")]
+    libdir = os.path.join(ROOT, "raytrace_amd", "lib")
+    cmd = ["gcc", "-O1", "-g", "-std=gnu11", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall", "-Wextra",
+           "-I", host, "-I", os.path.join(ROOT, "include"), "-o", exe, *srcs, "-L", libdir, "-lraytrace_amd", f"-Wl,-rpath,{libdir}", "-lm", "-lpthread"]
+    p = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    work = tmp_path / "work"
+    work.mkdir()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe, str(work)], capture_output=True, timeout=300, env=env)
+    assert p.returncode == 0 and b"host sanitize ok" in p.stdout, (p.stdout + p.stderr).decode()[-3000:]
