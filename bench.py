@@ -354,6 +354,8 @@ def main():
         while not args.no_ramp and time.perf_counter() - t_ramp < 0.5:
             step()
             torch.cuda.synchronize(dev)
+    if world > 1:
+        step()      # the first collective builds the communicator: never inside the timed steps, whatever --warmup says
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
