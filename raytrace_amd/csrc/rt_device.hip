@@ -287,11 +287,13 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
       const float4 ra = w.rays[3 * owner], rb = w.rays[3 * owner + 1];
       const double inv_a = *reinterpret_cast<const double *>(&w.rays[3 * owner + 2]);
       const float4 ex = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.exact) + off16);
+      // (the sphere's original index is fetched beside its geometry, not after the hit test: one memory latency per
+      // pass instead of two)
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(off4) : "s"(2u), "v"(entry));
+      const uint32_t original = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sc.orig) + off4);
       float t;
       if (exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, inv_a, ex.x, ex.y, ex.z, ex.w, w.tmin, kFltMax, t)) {
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(off4) : "s"(2u), "v"(entry));
-        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) |
-                                       *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sc.orig) + off4);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | original;
         atomicMin(&w.best[owner], key);
       }
     }
