@@ -30,7 +30,7 @@ job = rt.Job(1920, 1080, spp, seed=0)
 
 
 def words():
-    log = np.zeros(28, np.uint64)
+    log = np.zeros(30, np.uint64)
     rt.N.check(rt.N.device.rt_debug_wave_log(r._h, C.c_void_p(log.ctypes.data), len(log)), "wave_log")
     return log.astype(np.float64)
 
@@ -50,4 +50,7 @@ out["batch_visits_per_trip"] = d[24] / c["wave_iterations"]
 out["batches_picked_per_trip"] = d[25] / c["wave_iterations"]
 out["lane_batch_pairs_wanted_per_trip"] = d[26] / c["wave_iterations"]
 out["batches_wanted_by_some_lane_per_trip"] = d[27] / c["wave_iterations"]
+out["candidates_per_trip"] = c["candidates"] / c["wave_iterations"]
+out["candidates_with_a_root_in_range_per_trip"] = d[28] / c["wave_iterations"]
+out["candidates_at_scan_position_0_per_trip"] = d[29] / c["wave_iterations"]
 print(json.dumps(out, indent=1))

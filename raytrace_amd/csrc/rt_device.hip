@@ -173,7 +173,7 @@ struct HitState {
   uint32_t wave_groups;  // groups the wave scanned
   unsigned long long drain_cycles;   // shader cycles in the closing drain (profiling builds only)
 #if RT_EXP == 39
-  uint32_t fill[10];   // lanes at work and passes run: pair-filter passes, drain passes, always-group steps; [6] batch visits, [7] batches picked (streamed scenes)
+  uint32_t fill[12];   // lanes at work and passes run: pair-filter passes, drain passes, always-group steps; [6] batch visits, [7] batches picked (streamed scenes)
 #endif
 };
 
@@ -292,7 +292,12 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
       asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(off4) : "s"(2u), "v"(entry));
       const uint32_t original = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sc.orig) + off4);
       float t;
-      if (exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, inv_a, ex.x, ex.y, ex.z, ex.w, w.tmin, kFltMax, t)) {
+      const bool in_range = exact_hit(v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), ra.w, inv_a, ex.x, ex.y, ex.z, ex.w, w.tmin, kFltMax, t);
+#if RT_EXP == 39
+      h.fill[10] += (uint32_t)__popcll(__ballot(in_range));                      // candidates with a root in range
+      h.fill[11] += (uint32_t)__popcll(__ballot((entry & 0xffffu) == 0u));         // candidates at scan position 0
+#endif
+      if (in_range) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | original;
         atomicMin(&w.best[owner], key);
       }
@@ -1179,7 +1184,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   unsigned long long c_scan = 0, c_drain = 0, c_shade = 0;
 #if RT_EXP == 39
   // lanes at work / times executed, per part of the trip (wave-uniform counts)
-  uint32_t fill[28] = {};
+  uint32_t fill[30] = {};
   uint32_t lane_tries = 0;
 #define RT_FILL(K, MASK)                                   \
   do {                                                     \
@@ -1231,6 +1236,8 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
         fill[25] += h.fill[7];
         fill[26] += h.fill[8];
         fill[27] += h.fill[9];
+        fill[28] += h.fill[10];
+        fill[29] += h.fill[11];
         fill[6] += live;
         fill[7] += 1u;
 #endif
@@ -1457,7 +1464,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
 #if RT_EXP == 39
   fill[16] = (uint32_t)wave_sum((unsigned long long)lane_tries);
   if (lane == 0 && args.counters)
-    for (int k = 0; k < 28; ++k) atomicAdd(&args.counters[kWaveLogBase + k], (unsigned long long)fill[k]);
+    for (int k = 0; k < 30; ++k) atomicAdd(&args.counters[kWaveLogBase + k], (unsigned long long)fill[k]);
 #endif
 #undef RT_FILL
   // event counts: one atomic per wave and counter
