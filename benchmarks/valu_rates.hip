@@ -14,6 +14,12 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters
     for (int r = 0; r < 8; ++r) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        if (OP == 19) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dd[i]) : "v"(dd[(i + 1) & 7]), "v"(dd[(i + 3) & 7]));   // three different register pairs
+        if (OP == 20) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 3) & 7]));            // three different registers
+        if (OP == 21) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(dd[i]) : "v"(dd[(i + 1) & 7]), "v"(dd[(i + 3) & 7]));   // broadcast of one half, as the filter uses it
+        if (OP == 22) asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(dd[i]) : "v"(dd[(i + 1) & 7]), "v"(dd[(i + 3) & 7]));
+        if (OP == 23) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(dd[i]) : "v"(dd[(i + 1) & 7]), "v"(dd[(i + 3) & 7]));
+        if (OP == 24) asm volatile("v_add_f32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 3) & 7]));
         if (OP == 0 && (r * 8 + i) % 2 == 0) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
         if (OP == 0 && (r * 8 + i) % 2 == 1) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
         if (OP == 1 && (r * 8 + i) % 2 == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(dd[i]));
@@ -107,5 +113,11 @@ int main() {
   run<16>("cmp|add", d);
   run<17>("sub|mul", d);
   run<18>("lshr|xor", d);
+  run<19>("pk_fma 3 sources", d);
+  run<20>("fma 3 sources", d);
+  run<21>("pk_fma 3 src op_sel", d);
+  run<22>("pk_mul 2 sources", d);
+  run<23>("fma_f64 3 sources", d);
+  run<24>("add_f32 2 sources", d);
   return 0;
 }
