@@ -6,7 +6,7 @@
  * them where raytrace() fills its render_arg (after c/main.c:525) and swaps &render for &render_gpu
  * (c/main.c:534); the result, oracle/_ref/ray_ref_gpu, is the reference's own command line, scene builder,
  * camera and PPM writer around libraytrace_amd.so.  TEST INFRASTRUCTURE: it proves the drop-in compiles
- * and runs; nothing in the product path uses it.  The same text is shown in INTEGRATION.md.
+ * and runs; nothing in the product path uses it.  The integration guide shows this same text (a test compares them).
  */
 #include "rt_amd.h"
 

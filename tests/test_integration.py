@@ -1,4 +1,4 @@
-"""The drop-in, compiled: INTEGRATION.md's render_gpu() spliced into the reference translation unit
+"""The drop-in, compiled: the render_gpu() binding that the integration guide shows, spliced into the reference translation unit
 (oracle/Makefile, target `integration`) gives oracle/_ref/ray_ref_gpu, the reference's own CLI with its render
 threads bound to libraytrace_amd.so."""
 import os
