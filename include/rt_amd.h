@@ -146,7 +146,11 @@ int rt_ctx_synchronize(rt_ctx *ctx);
 
 /* Copies the sphere list to the device: stands in for the `scene*` that
  * raytrace() hands every render thread (c/main.c:499-501, 520).  Host
- * pointer; the list is immutable until the next upload. */
+ * pointer; the list is immutable until the next upload.  At most 65,535
+ * spheres, and at most 65,536 scan positions once the list is padded to whole
+ * groups and the much larger spheres have groups of their own (a scene of
+ * 65,535 similar spheres fits; RT_ERR_LIMIT otherwise).  Centres and radii
+ * must be finite. */
 int rt_scene_upload(rt_ctx *ctx, const rt_sphere *spheres, size_t n);
 
 /* render() of c/main.c:446-483 for the rows of `job`, asynchronous on the

@@ -2430,7 +2430,9 @@ int rt_scene_upload(rt_ctx *c, const rt_sphere *spheres, size_t n) {
   const rtcluster::Layout L = rtcluster::build_layout(spheres, n, kBatchSpheres);
   const uint32_t n_pad = L.n_scan;
   static_assert(rtcluster::kGroup == kChunk, "one group per chunk");
-  if (n_pad > kMaxSpheres) return fail(RT_ERR_LIMIT, "too many spheres after padding");
+  // (scan positions 0 .. 65535 fit the 16-bit fields; the padding that completes the last pair of super-groups, and
+  // the separate groups of much larger spheres, can push a scene of just under 65,536 spheres over)
+  if (n_pad > kMaxSpheres + 1u) return fail(RT_ERR_LIMIT, "more than 65536 scan positions after padding (" + std::to_string(n_pad) + ")");
   std::vector<float4> filter(n_pad), exact(n_pad), boxes(3 * (n_pad / 16)), sboxes(3 * (n_pad / 64)), geom_o(n), mat_o(n);
   std::vector<int32_t> type_o(n);
   std::vector<double> inv_r_o(n);

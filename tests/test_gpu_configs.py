@@ -182,3 +182,41 @@ def test_rays_outside_the_box_range_in_scenes_with_padded_quarters(renderer, rt,
     assert np.array_equal(got["rgb8"], want["rgb8"])
     assert np.array_equal(got["linear"].view(np.uint32), want["linear"].view(np.uint32))
     assert np.array_equal(got["first_hit"], want["first_hit"])
+
+
+def test_the_largest_scene_and_the_first_too_large(renderer, rt, oracle):
+    """65,535 spheres (128 batches: every bit of both batch masks, scan positions up to 65,535 in the 16-bit list
+    fields): closest hits and a small render against the oracle.  One sphere more, or a much larger sphere whose
+    group of its own pushes the padded length past 65,536, is RT_ERR_LIMIT with a message, not a wrong picture."""
+    rng = np.random.default_rng(65535)
+    n = 65535
+    sc = np.zeros(n, rt.SPHERE_DTYPE)
+    g = np.stack(np.meshgrid(np.arange(256), np.arange(256), indexing="ij"), -1).reshape(-1, 2)[:n]
+    sc["center"] = np.stack([g[:, 0] * 0.5 - 64 + rng.uniform(-0.1, 0.1, n), rng.uniform(0.1, 0.3, n), g[:, 1] * 0.5 - 64 + rng.uniform(-0.1, 0.1, n)], 1)
+    sc["radius"] = rng.uniform(0.08, 0.15, n)
+    sc["type"] = rng.integers(0, 3, n)
+    sc["albedo"] = rng.uniform(0.2, 0.9, (n, 3))
+    sc["param"] = np.where(sc["type"] == 2, 1.5, rng.uniform(0, 0.3, n))
+    renderer.upload(sc)
+    m = 4000
+    A = np.stack([rng.uniform(-60, 60, m), rng.uniform(0.05, 3.0, m), rng.uniform(-60, 60, m)], 1)
+    B = rng.normal(size=(m, 3))
+    B[:, 1] = -np.abs(B[:, 1]) * 0.2
+    rays = np.concatenate([A, B], 1).astype(np.float32)
+    assert _check_closest_hits(renderer, oracle, sc, rays) > 0.5
+    nx, ny, spp = 48, 27, 1
+    cam = rt.camera_new((20, 6, 12), (0, 0, 0), (0, 1, 0), 30.0, nx / ny, 0.0, 20.0)
+    got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=1))
+    want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=1, host_threads=16)
+    assert np.array_equal(got["rgb8"], want["rgb8"]) and np.array_equal(got["first_hit"], want["first_hit"])
+    too_many = np.concatenate([sc, sc[:1]])
+    with pytest.raises(rt.RtError) as e:
+        renderer.upload(too_many)
+    assert e.value.code == 5 and "65535" in str(e.value)
+    with_a_giant = sc.copy()
+    with_a_giant["radius"][0] = 50.0
+    with pytest.raises(rt.RtError) as e:
+        renderer.upload(with_a_giant)
+    assert e.value.code == 5 and "padding" in str(e.value)
+    renderer.upload(sc[:1000])                                   # the context is still usable
+    assert renderer.closest_hit(rays[:10])[0].shape == (10,)
