@@ -366,3 +366,38 @@ def test_sample_batches_do_not_change_the_sum(renderer, rt):
     assert np.array_equal(big["rgb8"][rows], part["rgb8"])
     assert np.array_equal(big["linear"][rows].view(np.uint32), part["linear"].view(np.uint32))
     assert np.array_equal(big["hit_sum"][rows], part["hit_sum"]) and np.array_equal(big["first_hit"][rows], part["first_hit"])
+
+
+def test_bad_jobs_and_scenes_are_error_codes(rt):
+    """Every rejection of check_job and rt_scene_upload comes back as a code with a message (include/rt_amd.h:
+    'never aborts'), and the context works afterwards."""
+    r = rt.Renderer(0)
+    cam = rt.camera_default(16, 8)
+    try:
+        with pytest.raises(rt.RtError) as e:
+            r.render_host(cam, rt.Job(16, 8, 1))
+        assert e.value.code == 3                                            # RT_ERR_NO_SCENE
+        sc = rt.small_scene()
+        bad = sc.copy()
+        bad["center"][3, 1] = np.nan
+        with pytest.raises(rt.RtError) as e:
+            r.upload(bad)
+        assert e.value.code == 1 and "not finite" in str(e.value)
+        bad = sc.copy()
+        bad["radius"][2] = np.inf
+        with pytest.raises(rt.RtError):
+            r.upload(bad)
+        r.upload(sc)
+        for kw, text in ((dict(nsamples=0), "nsamples"), (dict(max_depth=0), "max_depth"), (dict(tmin=-1.0), "tmin"),
+                         (dict(row0=8, tile_rows=2), "row0"), (dict(tile_rows=0), "no rows"), (dict(n_tiles=0), "no rows"),
+                         (dict(tile_rows=4, tile_stride=2, n_tiles=2), "overlap"), (dict(kernel=7), "kernel"), (dict(nx=0), "size"),
+                         (dict(nsamples=2, sample0=0xFFFFFFFF), "2^32")):
+            args = dict(nx=16, ny=8, nsamples=1)
+            args.update(kw)
+            with pytest.raises(rt.RtError) as e:
+                r.render_host(cam, rt.Job(**args))
+            assert e.value.code in (1, 5) and text in str(e.value), (kw, str(e.value))
+        got = r.render_host(cam, rt.Job(16, 8, 1))                          # still in working order
+        assert got["rgb8"].shape == (8, 16, 3)
+    finally:
+        r.close()
