@@ -5,7 +5,7 @@ set -eu
 cd "$(dirname "$0")/.."
 mkdir -p _out/exp
 for n in "$@"; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
     -DRT_EXP=$n -o _out/exp/lib_exp$n.so raytrace_amd/csrc/rt_device.hip &
 done
 wait

@@ -17,7 +17,9 @@ LIB = os.path.join(PKG, "lib")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: plain a*b+c must stay two roundings (see csrc/rt_core.h)
-HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+# max-ilp: the scheduler variant that favours instruction-level parallelism over register pressure; the trace kernel
+# is pinned to its register budget by __launch_bounds__ either way, and measures 0.9 % faster with it
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-std=c++17", "-fPIC", "-shared",
              "-Wall", "-Wno-unused-function"]
 C_FLAGS = ["-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra"]
 
