@@ -78,3 +78,30 @@ def test_scene_upload_between_queued_renders(rt, oracle):
             assert np.array_equal(out.cpu().numpy(), want), seed
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("scene,n", [("random_scene", None), ("random_scene", 30)])
+def test_profiling_build_of_the_kernel_renders_the_same_picture(rt, oracle, scene, n):
+    """RT_FLAG_PROFILE selects the instrumented instantiation of the trace kernel (cycle counts per phase, wave start
+    and end times): the same bits as the plain one, for a scene in LDS and for one scanned in place, and the cycle
+    counters it fills add up."""
+    sc = getattr(rt, scene)(n) if n else getattr(rt, scene)()
+    r = rt.Renderer(0)
+    try:
+        r.upload(sc)
+        nx, ny, spp = 160, 90, 3
+        cam = rt.camera_default(nx, ny)
+        plain = r.render_host(cam, rt.Job(nx, ny, spp, seed=2))
+        r.counters(reset=True)
+        prof = r.render_host(cam, rt.Job(nx, ny, spp, seed=2, flags=rt.FLAG_PROFILE))
+        c = r.counters()
+        for k in ("rgb8", "first_hit", "hit_sum"):
+            assert np.array_equal(plain[k], prof[k]), k
+        assert np.array_equal(plain["linear"].view(np.uint32), prof["linear"].view(np.uint32))
+        want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=2, host_threads=16)
+        assert np.array_equal(prof["rgb8"], want["rgb8"])
+        assert c["paths"] == nx * ny * spp and c["cycles_total"] > 0
+        assert c["cycles_scan"] + c["cycles_drain"] + c["cycles_shade"] <= c["cycles_total"]
+        assert c["first_wave_start"] <= c["last_wave_start"] <= c["last_wave_end"] and c["first_wave_end"] <= c["last_wave_end"]
+    finally:
+        r.close()
