@@ -269,6 +269,12 @@ def main():
     if not launched and args.gpus > 1:
         sys.exit(self_launch(args))
 
+    # Standard output carries the one JSON line and nothing else: whatever libraries print there while they start up
+    # (the gloo backend announces its peers on stdout) goes to standard error instead.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -504,7 +510,8 @@ def main():
                                                    "the same rocprofv3 pass (GRBM_GUI_ACTIVE is summed over the 8 XCDs)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, scene_name, half_extent, max_depth)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
