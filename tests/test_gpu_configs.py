@@ -220,3 +220,46 @@ def test_the_largest_scene_and_the_first_too_large(renderer, rt, oracle):
     assert e.value.code == 5 and "padding" in str(e.value)
     renderer.upload(sc[:1000])                                   # the context is still usable
     assert renderer.closest_hit(rays[:10])[0].shape == (10,)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_scenes_and_cameras(renderer, rt, oracle, case):
+    """Scenes nobody arranged: sizes on both sides of every structural boundary, radii over five orders of magnitude
+    (tiny ones and many large ones go to the always-scanned groups), duplicated spheres (equal hit distances: the
+    lowest index must win), spheres far from the origin, cameras inside spheres -- small renders against the oracle."""
+    rng = np.random.default_rng(9000 + case)
+    n = int(rng.choice([3, 40, 130, 257, 600, 1025, 1500, 2047, 2100, 3000, 5000, 9000]))
+    sc = np.zeros(n, rt.SPHERE_DTYPE)
+    spread = float(rng.choice([3.0, 12.0, 60.0]))
+    sc["center"] = rng.uniform(-spread, spread, (n, 3)) + (rng.choice([0.0, 0.0, 5000.0]) if case % 4 == 3 else 0.0)
+    sc["radius"] = np.exp(rng.uniform(np.log(0.02), np.log(0.6), n))
+    big = rng.choice(n, size=min(n, int(rng.choice([0, 1, 5, 40]))), replace=False)
+    sc["radius"][big] *= rng.uniform(5, 40, len(big))
+    tiny = rng.choice(n, size=min(n, 3), replace=False)
+    sc["radius"][tiny] = 1e-6
+    dup = rng.choice(n, size=n // 10, replace=False)
+    src = rng.choice(n, size=n // 10, replace=True)
+    sc["center"][dup] = sc["center"][src]
+    sc["radius"][dup] = sc["radius"][src]
+    sc["type"] = rng.integers(0, 3, n)
+    sc["albedo"] = rng.uniform(0.1, 0.95, (n, 3))
+    sc["param"] = np.where(sc["type"] == 2, rng.choice([1.3, 1.5, 2.4], n), rng.uniform(0, 0.5, n))
+    renderer.upload(sc)
+    c0 = sc["center"].mean(0)
+    nx, ny, spp = 40, 24, 2
+    for view in range(2):
+        if view == 0:
+            look_from = c0 + rng.normal(size=3) * spread * 1.5
+        else:                                                   # inside (or on the skin of) some sphere
+            k = int(rng.integers(0, n))
+            look_from = sc["center"][k] + rng.normal(size=3) * sc["radius"][k] * 0.5
+        cam = rt.camera_new(tuple(look_from), tuple(c0), (0, 1, 0), float(rng.uniform(15, 70)), nx / ny, float(rng.choice([0.0, 0.1])),
+                            float(np.linalg.norm(look_from - c0) + 0.1))
+        depth = int(rng.choice([4, 50]))
+        got = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=case, max_depth=depth))
+        full = renderer.render_host(cam, rt.Job(nx, ny, spp, seed=case, max_depth=depth, flags=rt.FLAG_FULL_SCAN))
+        want = oracle.render_det(cam.as_array(), as_oracle_scene(sc), nx, ny, spp, seed=case, max_depth=depth, host_threads=16)
+        for k in ("rgb8", "first_hit", "hit_sum"):
+            assert np.array_equal(got[k], want[k]), (case, view, k)
+            assert np.array_equal(full[k], want[k]), (case, view, k, "full scan")
+        assert np.array_equal(got["linear"].view(np.uint32), want["linear"].view(np.uint32)), (case, view)
