@@ -6,9 +6,10 @@
 // "first root inside (tmin, FLT_MAX)" over all spheres, and among equal t the
 // lowest index wins (strict `<`, c/main.c:225, 249-251).  The kernels
 // therefore scan in an order of their own -- large spheres first, the rest
-// split recursively along the longest axis into groups of kGroup neighbours,
-// every split at an aligned group boundary so that aligned runs of groups are
-// compact regions -- and break ties by the original index.
+// split recursively into groups of kGroup neighbours (every split at an
+// aligned group boundary, along the axis that leaves the smaller boxes, so
+// that aligned runs of groups are compact regions) -- and break ties by the
+// original index.
 //
 // Each group of regular spheres has an axis-aligned box; a ray that misses the
 // box on its half line t >= 0 skips the group (test and proof obligations in
@@ -88,8 +89,7 @@ inline Layout build_layout(const rt_sphere *s, size_t n, size_t batch_spheres) {
   for (size_t i = 0; i < n; ++i)
     ((double)radii[i] > kLargeFactor * median || !((double)radii[i] >= kTinyRadius) ? large : regular).push_back((uint32_t)i);
 
-  // Order of the regular spheres: recursive split along the longest axis of the centres until a part is one
-  // group.  The split point is not the median but the most aligned group boundary inside the part, counted
+  // Order of the regular spheres: recursive split until a part is one group.  The split point is not the median but the most aligned group boundary inside the part, counted
   // in scan positions of the whole list (the large spheres' groups come first): the multiple of the
   // largest power of two that falls strictly inside.  Every aligned run of 2, 4, 64 groups -- a round, a
   // super-group, a batch of the kernels -- is then a subtree, i.e. one compact region, instead of the end
@@ -110,18 +110,6 @@ inline Layout build_layout(const rt_sphere *s, size_t n, size_t batch_spheres) {
         for (size_t k = b0; k < e0; ++k) ordered.push_back(regular[k]);
         continue;
       }
-      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-      for (size_t k = b0; k < e0; ++k)
-        for (int d = 0; d < 3; ++d) {
-          lo[d] = std::min(lo[d], (double)s[regular[k]].center[d]);
-          hi[d] = std::max(hi[d], (double)s[regular[k]].center[d]);
-        }
-      int ax = 0;
-      for (int d = 1; d < 3; ++d)
-        if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
-      std::sort(regular.begin() + b0, regular.begin() + e0, [&](uint32_t a, uint32_t c) {
-        return s[a].center[ax] != s[c].center[ax] ? s[a].center[ax] < s[c].center[ax] : a < c;
-      });
       const size_t groups = (cnt + kGroup - 1) / kGroup, g1 = part.g0 + groups;   // (groups >= 2)
       size_t mid = part.g0 + 1;
       for (size_t pw = (size_t)1 << 30; pw >= 1; pw >>= 1) {
@@ -132,6 +120,34 @@ inline Layout build_layout(const rt_sphere *s, size_t n, size_t batch_spheres) {
         }
       }
       const size_t left = (mid - part.g0) * kGroup;
+      // Along which axis: the one that leaves the two parts with the smallest boxes, each box's surface weighted by
+      // the number of spheres behind it (the chance that a ray meets a box goes with its surface).
+      auto by_axis = [&](int ax) {
+        std::sort(regular.begin() + b0, regular.begin() + e0, [&](uint32_t a, uint32_t c) {
+          return s[a].center[ax] != s[c].center[ax] ? s[a].center[ax] < s[c].center[ax] : a < c;
+        });
+      };
+      auto surface = [&](size_t first, size_t last) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (size_t k = first; k < last; ++k)
+          for (int d = 0; d < 3; ++d) {
+            lo[d] = std::min(lo[d], (double)s[regular[k]].center[d] - (double)s[regular[k]].radius);
+            hi[d] = std::max(hi[d], (double)s[regular[k]].center[d] + (double)s[regular[k]].radius);
+          }
+        const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x * y + y * z + z * x;
+      };
+      int best_ax = 0;
+      double best_cost = 1e300;
+      for (int ax = 0; ax < 3; ++ax) {
+        by_axis(ax);
+        const double cost = surface(b0, b0 + left) * (double)left + surface(b0 + left, e0) * (double)(cnt - left);
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_ax = ax;
+        }
+      }
+      if (best_ax != 2) by_axis(best_ax);
       stack.push_back(Part{b0 + left, e0, mid});   // popped second: the left part comes first in the order
       stack.push_back(Part{b0, b0 + left, part.g0});
     }
