@@ -1087,15 +1087,21 @@ __device__ __forceinline__ uint32_t global_row(const rt_job &job, uint32_t lr, u
 // Every path's radiance goes to rad[s][pixel] (with its first-hit index in
 // the fourth word); resolve_kernel then adds each pixel's samples in sample
 // order, which is the reference's summation order (c/main.c:462-469).
+// Chunk sizes (multiples of 64).  Large chunks keep a wave on one tile for many samples (coherent rays: 1024 ids
+// are 16 samples of a tile) and cost fewer queue operations, but the launch ends later: the last chunks handed
+// out are still being worked on when most waves have left.  A launch that another one follows on the other
+// stream (the next sample batch of the frame, or the next frame of a caller that queues them back to back) has that
+// tail covered and takes the large size (1.21e10 against 1.185e10 paths/s on the reference's final scene); a
+// launch on its own takes the small one (11.56 ms against 11.97).  Handing the last ids out in still smaller
+// pieces, which an earlier build did, costs more than it evens out now that rows of tiles are taken bottom-up
+// (the last paths are the sky's, the shortest).
 #ifndef RT_CHUNK_ITEMS
-#define RT_CHUNK_ITEMS 512
+#define RT_CHUNK_ITEMS 1024
 #endif
-#ifndef RT_TAIL_PATHS
-#define RT_TAIL_PATHS 4
+#ifndef RT_CHUNK_ALONE
+#define RT_CHUNK_ALONE 512
 #endif
-constexpr uint32_t kChunkItems = RT_CHUNK_ITEMS;
-constexpr uint32_t kTailChunkItems = 64;      // chunk size for the last paths of a launch
-constexpr uint32_t kTailPathsPerLane = RT_TAIL_PATHS;     // how many paths per lane of the grid are handed out in small chunks
+constexpr uint32_t kChunkItems = RT_CHUNK_ITEMS, kChunkAlone = RT_CHUNK_ALONE;
 
 // image and queue geometry of a launch: what handing out new paths needs
 struct PathGeom {
@@ -1106,7 +1112,7 @@ struct PathGeom {
   uint32_t batch;         // SB: samples in this batch
   uint32_t total_items;   // tiles * SB * 64
   uint32_t last_tile_row; // ceil(rows / 8) - 1
-  uint32_t big_end;       // ids below this (a multiple of kChunkItems) go out in large chunks, the rest in small ones
+  uint32_t chunk;         // ids a wave takes from the queue at a time
   uint32_t tile_rows_magic;  // see global_row
   double inv_nx, inv_ny;  // 1.0 / (double)(float)nx, ny (pixel_xy_by)
 };
@@ -1117,7 +1123,7 @@ struct TraceArgs {
   PathGeom geo;
   DeviceScene sc;
   float4 *rad;            // [SB][rows*nx] {r, g, b, first-hit index bits}
-  unsigned int *queue;    // two words: next unclaimed id of the large chunks, and of the small ones (less big_end)
+  unsigned int *queue;    // next unclaimed id (two words are kept per buffer; the second is unused)
   unsigned long long *counters;
 };
 
@@ -1163,7 +1169,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
   }
 
   // wave-uniform queue state
-  uint32_t pool_next = 0, pool_end = 0, take = kChunkItems;
+  uint32_t pool_next = 0, pool_end = 0;
   // where the chunk in hand starts: its first (tile, sample) index and that index split into tile, sample
   // and the tile into row and column of tiles -- one set of divisions per chunk instead of per path
   uint32_t pool_ts0 = 0, pool_tile0 = 0, pool_s0 = 0, pool_ty0 = 0, pool_tx0 = 0;
@@ -1297,26 +1303,10 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
       const PathGeom geo = kernarg_now<PathGeom>(offsetof(TraceArgs, geo));
       const rt_job &jb = geo.job;
       if (pool_next == pool_end) {
-        // Ids below geo.big_end are handed out kChunkItems at a time from the first queue word; the last
-        // few paths per lane of the launch, 64 at a time from the second: a wave that takes the last large
-        // chunk would otherwise still be at work on it long after the others have left (the launch ended
-        // with a tenth of its duration spent waiting for such waves).
-        uint32_t base = 0, limit = geo.big_end;
-        for (;;) {   // (two turns on the trip that finds the large chunks gone)
-          if (lane == 0) {
-            unsigned int amount = take;
-            asm volatile("" : "+v"(amount));   // (not a loop invariant held in a vector register)
-            base = atomicAdd(kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)) + (take == kChunkItems ? 0 : 1), amount);
-          }
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          if (take != kChunkItems) {
-            base += geo.big_end;
-            limit = geo.total_items;
-            break;
-          }
-          if (base < geo.big_end) break;
-          take = kTailChunkItems;
-        }
+        uint32_t base = 0;
+        const uint32_t limit = geo.total_items, take = geo.chunk;
+        if (lane == 0) base = atomicAdd(kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)), take);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= limit) {
           exhausted = true;
         } else {
@@ -1336,7 +1326,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
         const uint32_t id = pool_next + rank;
         const uint32_t l = id & 63u, ts = id >> 6;
         // (tile, sample) and (tile row, tile column) by stepping from the chunk's start: a chunk spans
-        // at most kChunkItems / 64 + 1 consecutive ts values, so the loops run once or not at all
+        // at most chunk / 64 + 1 consecutive ts values, so the loops run a few times at most
         // unless the batch or the image is only a few units wide
         uint32_t s_local = pool_s0 + (ts - pool_ts0), tx = pool_tx0, ty = pool_ty0;
         while (s_local >= geo.batch) {
@@ -2173,16 +2163,19 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Work
                             ? (uint32_t)(((1ull << 32) + job->tile_rows - 1) / job->tile_rows)
                             : 0u;
     t.geo.total_items = tiles_x * tiles_y * sb * 64u;
-    {
-      const uint64_t tail = (uint64_t)grid.x * kBlockThreads * kTailPathsPerLane;
-      t.geo.big_end = t.geo.total_items > tail ? (uint32_t)((t.geo.total_items - tail) / kChunkItems) * kChunkItems : 0u;
-    }
     // which radiance buffer, and on which stream the trace runs
     const bool piped = piped_render;
     const int buf = piped ? (int)(c->batches_launched & 1u) : 0;
     hipStream_t ts = piped ? c->trace_stream[buf] : c->stream;
     t.rad = ws.rad[buf];
     t.queue = ws.queue + 2 * buf;
+    {
+      // will this launch's last waves have company?  Yes if another batch of this render follows, or if the launch
+      // before it is still at work (a caller that queues renders back to back)
+      const bool followed = s0 + sb < job->nsamples;
+      const bool behind = piped && c->batches_launched > 0 && hipEventQuery(c->ev_traced[buf ^ 1]) == hipErrorNotReady;
+      t.geo.chunk = piped && (followed || behind) ? kChunkItems : kChunkAlone;
+    }
     // (the resolve that last read this buffer must be done before the trace overwrites it)
     if (piped && c->resolved_recorded[buf]) RT_HIP(hipStreamWaitEvent(ts, c->ev_resolved[buf], 0));
     RT_HIP(hipMemsetAsync(t.queue, 0, 2 * sizeof(unsigned int), ts));
