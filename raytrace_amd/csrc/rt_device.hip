@@ -5,7 +5,8 @@
 // full.  One trip of its loop is one bounce of every live lane:
 //   (1) closest hit.  The sphere list sits in LDS in scan order (rt_cluster.h)
 //       as 32-byte sphere pairs.  Every lane's half line is tested against the
-//       boxes of the super-groups and, where some lane can touch one, of its
+//       boxes of the quarters (128 positions), of the super-groups of a quarter
+//       some lane can touch and, likewise one level down, of the super-groups'
 //       groups of eight spheres; a lane whose ray can touch a group lists
 //       (lane, group).  The listed pairs are then filtered 64 at a time by
 //       whichever lanes are free: 32 packed FMAs per pair (the eight-FMA
