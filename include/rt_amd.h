@@ -168,7 +168,7 @@ int rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_job *job,
  * bytes; the kernels' scratch (per-path radiance, per-pixel running sums, the work-queue head, the event
  * counts) lives in one array of RT_STATIC_SCRATCH_BYTES that the library holds statically on every GPU
  * it runs on, so the call makes no hipMalloc/hipFree and creates nothing.  Limits: the megakernel only
- * (RT_KERNEL_MEGA), no RT_FLAG_PROGRESSIVE, the scene uploaded beforehand, and
+ * (RT_KERNEL_MEGA), no RT_FLAG_PROGRESSIVE, no RT_FLAG_PROFILE, the scene uploaded beforehand, and
  * rt_job_rows(job) * nx <= RT_STATIC_MAX_PIXELS (render larger frames in row bands); beyond that it
  * returns RT_ERR_LIMIT.  Samples beyond what the scratch holds at once are rendered in batches.  Every
  * call on a GPU uses that GPU's one array: calls that overlap on one GPU (two contexts, two streams)

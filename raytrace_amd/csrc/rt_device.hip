@@ -78,6 +78,53 @@ using namespace rtcore;
     if (RT_EXP == N) h.drain_cycles -= tick() - hstage_x0_##N; \
   } while (0)
 
+// RT_EXP 51..58: LDS bank-conflict attribution.  One kind of LDS access is issued a second time (same addresses,
+// result thrown away); the growth of SQ_LDS_BANK_CONFLICT and SQ_LDS_IDX_ACTIVE over the plain build is that
+// access kind's share.  51 ray table read by owner (pair filter), 52 pair image read by group (pair filter; scenes
+// resident in LDS), 53 ray table read by owner (exact evaluation), 54 the 64-bit minimum on best[owner], 55 the
+// (lane, group) list and group-size reads, 56 the (lane, group) list writes, 57 the (lane, sphere) list writes and
+// reads, 58 the per-lane ray table and key writes.
+#define RT_LDS_EXP (RT_EXP >= 51 && RT_EXP <= 58)
+#if RT_LDS_EXP
+typedef float rt_f32x4 __attribute__((ext_vector_type(4)));
+typedef float rt_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const unsigned char lds_bytes;
+__device__ __forceinline__ uint32_t lds_address(const void *p) { return (uint32_t)(uintptr_t)(lds_bytes *)p; }
+__device__ __forceinline__ void lds_again_read_b128(uint32_t a) {
+  rt_f32x4 x;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_again_read_b64(uint32_t a) {
+  rt_f32x2 x;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_again_read_b32(uint32_t a) {
+  uint32_t x;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_again_read_u16(uint32_t a) {
+  uint32_t x;
+  asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_again_read_u8(uint32_t a) {
+  uint32_t x;
+  asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_again_write_b16(uint32_t a, uint32_t v) {
+  asm volatile("ds_write_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_again_write_b32(uint32_t a, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_again_write_b64(uint32_t a, unsigned long long v) {
+  asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_again_write_b128(uint32_t a, float4 v) {
+  const rt_f32x4 x = {v.x, v.y, v.z, v.w};
+  asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(a), "v"(x) : "memory");
+}
+#endif
+
 namespace {
 
 // ----------------------------------------------------------------- limits
@@ -198,36 +245,58 @@ __device__ __forceinline__ FilterRay dead_ray() {
 // (lane, sphere) entries per wave.  The full scan adds up to 64 * kChunk per chunk and drains when fewer
 // are free; the culled scan looks at what a pass produced before appending it (filter_listed_pairs) and
 // gets by with a list that 32 lanes' worth of entries fit.
-constexpr uint32_t kWaveListCapFull = 768, kWaveListCapCull = 320;
+constexpr uint32_t kWaveListCapFull = 768, kWaveListCapCull = 288;
 constexpr uint32_t wave_list_cap(bool cull) { return cull ? kWaveListCapCull : kWaveListCapFull; }
 constexpr uint32_t kWaveListFlushFull = kWaveListCapFull - 64u * kChunk;   // drain above this before a chunk
 static_assert(kWaveListCapFull >= 64u * kChunk && kWaveListCapCull >= 32u * kChunk, "list too short");
-constexpr uint32_t kPairListCap = 280;              // (lane, group) entries per wave, 16 bits each (with this the
-                                                    // workgroup's LDS is 31,968 bytes for a 512-position scene: five fit
-                                                    // a CU's 160 KiB, which is handed out in 1280-byte units)
+constexpr uint32_t kPairListCap = 280;              // (lane, group) entries per wave, 16 bits each (with this and a
+                                                    // (lane, sphere) list of 288 the workgroup's LDS is 31,968 bytes for a
+                                                    // 512-position scene: five fit a CU's 160 KiB, which is handed out
+                                                    // in 1280-byte units)
 constexpr uint32_t kPairListFlush = kPairListCap - 2u * 64u;       // a round adds at most two groups for 64 lanes
+
+// The per-lane ray table.  Any lane of a wave reads any other lane's ray from it (the lists name an owner), so
+// what matters is how 32 or 16 arbitrary owners fall on the LDS banks.  Eight-byte entries, 64 owners to a row of
+// 512 bytes, read with ds_read_b64: that instruction serves 32 lanes per cycle over 64 banks, so only owners o and
+// o + 32 share banks and a read costs at most twice its conflict-free time whatever the owners are.  (As 48 bytes
+// per lane read by the compiler's choice of ds_read2_b32 / ds_read_b96 -- 32 banks, twelve-dword stride: only eight
+// distinct bank positions -- every read of 32 owners was a four-way conflict or worse.)
+constexpr uint32_t kRayRows = 6, kRayRowBytes = 64u * 8u;
+typedef float rt_v2f __attribute__((ext_vector_type(2)));
 
 struct ScanLds {
   float4 *pairs;
   float4 *boxes;                 // 3 per round (16 spheres)
   float4 *sboxes;                // 3 per pair of super-groups (64 spheres)
   float4 *qboxes;                // 3 per pair of quarters (256 spheres)
-  float4 *rays;                  // 3 per lane: {A, a}, {B, -(B.B) of the filter}, {1/a as a double, A.B, naaa of the filter}
+  float2 *rays;                  // per wave six rows of 64 eight-byte entries, one entry per lane and row (ray_table_*):
+                                 // {Ax, Ay}, {Az, a}, {Bx, By}, {Bz, -(B.B) of the filter}, {1/a as a double},
+                                 // {A.B, naaa of the filter}
   unsigned long long *best;      // 1 per lane
   uint32_t *wlist;               // wave_list_cap() per wave: (owner lane << 16) | scan position
   uint16_t *plist;               // kPairListCap per wave: (group within the batch << 6) | owner lane
   uint8_t *real8;                // per group of the batch: its real (non-pad) spheres
 };
 
+// The pair image in LDS has one unused 16-byte entry after every two groups (16 entries, 256 bytes).  The pair
+// filter reads entry k of a group per lane, each lane its own group; ds_read_b128 serves 16 lanes per cycle over
+// the 16 sixteen-byte slots of a 256-byte bank row, and without the gap entry k of every group of the same parity
+// lies in the same slot (a group is 128 bytes): different groups in one pass were served one after the other.
+// With the gap, entry k of group g lies in slot (8 g + (g >> 1) + k) mod 16, distinct for 16 consecutive groups.
+// An image read in place from global memory (scenes too large for LDS) has no gaps.
+template <bool kInPlace>
+__device__ __host__ __forceinline__ uint32_t pair_slot(uint32_t entry) { return kInPlace ? entry : entry + (entry >> 4); }
+__device__ __host__ inline uint32_t pair_image_entries(uint32_t entries) { return entries + entries / 16u; }
+
 template <bool kCull>
 __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entries) {
   ScanLds l;
   l.pairs = reinterpret_cast<float4 *>(smem);
-  l.boxes = l.pairs + entries;
+  l.boxes = l.pairs + pair_image_entries(entries);
   l.sboxes = l.boxes + 3u * (entries / 16u);
   l.qboxes = l.sboxes + 3u * (entries / 64u);
-  l.rays = l.qboxes + 3u * quarter_pairs(entries);
-  l.best = reinterpret_cast<unsigned long long *>(l.rays + 3 * kBlockThreads);
+  l.rays = reinterpret_cast<float2 *>(l.qboxes + 3u * quarter_pairs(entries));
+  l.best = reinterpret_cast<unsigned long long *>(l.rays + kRayRows * kBlockThreads);
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
   l.plist = reinterpret_cast<uint16_t *>(l.wlist + (kBlockThreads / 64) * wave_list_cap(kCull));
   l.real8 = reinterpret_cast<uint8_t *>(l.plist + (kBlockThreads / 64) * kPairListCap);
@@ -236,7 +305,7 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
 
 __device__ __forceinline__ void stage_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
                                             uint32_t tid) {
-  for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[i] = sc.filter[base + i];
+  for (uint32_t i = tid; i < count; i += kBlockThreads) lds.pairs[pair_slot<false>(i)] = sc.filter[base + i];
   for (uint32_t i = tid; i < 3u * (count / 16u); i += kBlockThreads) lds.boxes[i] = sc.boxes[3u * (base / 16u) + i];
   for (uint32_t i = tid; i < 3u * (count / 64u); i += kBlockThreads) lds.sboxes[i] = sc.sboxes[3u * (base / 64u) + i];
   for (uint32_t i = tid; i < 3u * quarter_pairs(count); i += kBlockThreads) lds.qboxes[i] = sc.qboxes[3u * (base / 256u) + i];
@@ -251,7 +320,7 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 struct WaveScan {
   uint32_t wlist_off;            // LDS byte address of this wave's (lane, sphere) list (wave-uniform, in a scalar register)
   uint32_t plist_off;            // the same for its (lane, group) list
-  const float4 *rays;            // this wave's 64 rays (lane l at [3l] .. [3l+2])
+  uint32_t rays_off;             // LDS byte address of this wave's ray table (wave-uniform, in a scalar register)
   unsigned long long *best;      // this wave's 64 keys
   uint32_t wcnt;                 // entries in the (lane, sphere) list (wave-uniform)
   uint32_t pcnt;                 // entries in the (lane, group) list (wave-uniform)
@@ -259,6 +328,23 @@ struct WaveScan {
   uint32_t lane16;               // lane << 16, the owner field of a (lane, sphere) entry
   float tmin;                    // of the query (wave-uniform)
 };
+
+// Five rows of the owner's entry of the ray table (addr = table + 8 * owner), as five ds_read_b64 in one block that
+// ends with the wait for them: written out because the compiler, left to itself, pairs such loads into
+// ds_read2_b64 / ds_read2_b32, which are served over 32 banks at half the rate.
+template <int kA, int kB, int kC, int kD, int kE>
+__device__ __forceinline__ void ray_table_read5(uint32_t addr, rt_v2f &a, rt_v2f &b, rt_v2f &c, rt_v2f &d, rt_v2f &e) {
+  asm volatile("ds_read_b64 %0, %5 offset:%6\n\t"
+               "ds_read_b64 %1, %5 offset:%7\n\t"
+               "ds_read_b64 %2, %5 offset:%8\n\t"
+               "ds_read_b64 %3, %5 offset:%9\n\t"
+               "ds_read_b64 %4, %5 offset:%10\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e)
+               : "v"(addr), "n"(kA * (int)kRayRowBytes), "n"(kB * (int)kRayRowBytes), "n"(kC * (int)kRayRowBytes), "n"(kD * (int)kRayRowBytes),
+                 "n"(kE * (int)kRayRowBytes)
+               : "memory");
+}
 
 // Exact evaluation (c/main.c:214-236) of the listed (lane, sphere) pairs, 64
 // pairs at a time whichever lanes they belong to: a lane's candidates are few
@@ -279,14 +365,25 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
 #endif
     if (e < w.wcnt) {
       const uint32_t entry = *(lds_u32 *)(uintptr_t)(w.wlist_off + (e << 2));
+#if RT_EXP == 57
+      lds_again_read_b32(w.wlist_off + (e << 2));
+#endif
       const uint32_t owner = entry >> 16;
       // byte offsets of the sphere's entries: (entry & 0xffff) << 4 and << 2, one instruction each with
       // the shift count in a scalar register (the compiler's form of the same instruction keeps the
       // count in a vector register for the whole kernel)
       uint32_t off16, off4;
       asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(off16) : "s"(4u), "v"(entry));
-      const float4 ra = w.rays[3 * owner], rb = w.rays[3 * owner + 1];
-      const double inv_a = *reinterpret_cast<const double *>(&w.rays[3 * owner + 2]);
+      rt_v2f r0, r1, r2, r3, r4;
+      ray_table_read5<0, 1, 2, 3, 4>(w.rays_off + (owner << 3), r0, r1, r2, r3, r4);
+#if RT_EXP == 53
+      {
+        rt_v2f x0, x1, x2, x3, x4;
+        ray_table_read5<0, 1, 2, 3, 4>(w.rays_off + (owner << 3), x0, x1, x2, x3, x4);
+      }
+#endif
+      const float4 ra = make_float4(r0[0], r0[1], r1[0], r1[1]), rb = make_float4(r2[0], r2[1], r3[0], r3[1]);
+      const double inv_a = __hiloint2double(__float_as_int(r4[1]), __float_as_int(r4[0]));
       const float4 ex = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.exact) + off16);
       // (the sphere's original index is fetched beside its geometry, not after the hit test: one memory latency per
       // pass instead of two)
@@ -301,6 +398,9 @@ __device__ __forceinline__ void drain_wave(const DeviceScene &sc, WaveScan &w, H
       if (in_range) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | original;
         atomicMin(&w.best[owner], key);
+#if RT_EXP == 54
+        atomicMin(&w.best[owner], key);
+#endif
       }
     }
   }
@@ -515,9 +615,11 @@ struct ChunkRegs {
   float4 q[kChunk];
 };
 
+template <bool kInPlace>
 __device__ __forceinline__ void load_chunk(ChunkRegs &r, const float4 *lds_pairs, uint32_t first) {
+  const float4 *src = lds_pairs + pair_slot<kInPlace>(first);   // (first is a multiple of kChunk: a group has no gap inside)
 #pragma unroll
-  for (int u = 0; u < kChunk; ++u) r.q[u] = lds_pairs[first + u];
+  for (int u = 0; u < kChunk; ++u) r.q[u] = src[u];
 }
 
 // filter the kChunk spheres held in r (scan positions first_index..+kChunk-1)
@@ -567,6 +669,7 @@ __device__ __forceinline__ void filter_chunk(const ChunkRegs &r, uint32_t first_
 // (neighbouring list entries mostly name the same group, so most of these reads are broadcasts) and
 // evaluates the same 32 packed FMAs as the full scan does, hence the same bits.  Spheres that pass go
 // to the (lane, sphere) list under the owner's name.
+template <bool kInPlace>
 __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const float4 *lds_pairs, const uint8_t *lds_real8,
                                                     uint32_t base, WaveScan &w, HitState &h) {
   RT_HSTAGE_BEGIN(38);
@@ -577,17 +680,30 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
     const bool valid = w.lane < width && e < w.pcnt;
     const uint32_t entry = valid ? (uint32_t)*(lds_u16 *)(uintptr_t)(w.plist_off + (e << 1)) : 0u;
     const uint32_t owner = entry & 63u, grp = entry >> 6;
-    const float4 ra = w.rays[3 * owner], rb = w.rays[3 * owner + 1], rc = w.rays[3 * owner + 2];
+    rt_v2f r0, r1, r2, r3, r5;
+    ray_table_read5<0, 1, 2, 3, 5>(w.rays_off + (owner << 3), r0, r1, r2, r3, r5);
+#if RT_EXP == 55
+    if (valid) lds_again_read_u16(w.plist_off + (e << 1));
+#endif
+#if RT_EXP == 51
+    {
+      rt_v2f x0, x1, x2, x3, x5;
+      ray_table_read5<0, 1, 2, 3, 5>(w.rays_off + (owner << 3), x0, x1, x2, x3, x5);
+    }
+#endif
     FilterRayP f;
-    f.p0 = f32x2{-rb.x, -rb.y};
-    f.p1 = f32x2{-rb.z, rc.z};
-    f.p2 = f32x2{-2.0f * ra.x, -2.0f * ra.y};
-    f.p3 = f32x2{-2.0f * ra.z, rb.w};
-    f.p4 = f32x2{rc.w, 0.0f};
+    f.p0 = f32x2{-r2[0], -r2[1]};
+    f.p1 = f32x2{-r3[0], r5[0]};
+    f.p2 = f32x2{-2.0f * r0[0], -2.0f * r0[1]};
+    f.p3 = f32x2{-2.0f * r1[0], r3[1]};
+    f.p4 = f32x2{r5[1], 0.0f};
     // A group's real spheres come first.  The second half of the groups is skipped when no pair of the
     // pass names a group with more than four -- as in the pass over the group of the few large
     // spheres, which every ray lists and which therefore fills a pass of its own.
     const uint32_t real = valid ? (uint32_t)lds_real8[grp] : 0u;
+#if RT_EXP == 55
+    if (valid && sc.n_pad <= kMaxLdsSpheres) lds_again_read_u8(lds_address(&lds_real8[grp]));
+#endif
     const bool upper_half = __ballot(real > (uint32_t)(kChunk / 2)) != 0ull;
     f32x2 d[kChunk / 2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
     // first word of this lane's entries: owner | scan position of the group's first sphere
@@ -603,8 +719,12 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       if (half == 0 || upper_half) {
-        const float4 *src = lds_pairs + grp * kChunk + 4 * half;
+        const float4 *src = lds_pairs + pair_slot<kInPlace>(grp * kChunk) + 4 * half;
         const float4 q[4] = {src[0], src[1], src[2], src[3]};
+#if RT_EXP == 52
+        if (sc.n_pad <= kMaxLdsSpheres)
+          for (int j = 0; j < 4; ++j) lds_again_read_b128(lds_address(&src[j]));
+#endif
         filter_two_pairs(f, q, d[2 * half], d[2 * half + 1]);
 #pragma unroll
         for (int u = 4 * half; u < 4 * half + 4; ++u) m[u] = __ballot(d[u >> 1][u & 1] > 0.0f) & valid_mask;
@@ -638,6 +758,9 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
           asm("" : "+s"(tail));   // keep it one scalar operand
           lds_u32 *dst = (lds_u32 *)(uintptr_t)(tail + (rank << 2));
           if (d[u >> 1][u & 1] > 0.0f && valid) *dst = word0 + (uint32_t)u;
+#if RT_EXP == 57
+          if (d[u >> 1][u & 1] > 0.0f && valid) lds_again_write_b32(tail + (rank << 2), word0 + (uint32_t)u);
+#endif
           w.wcnt += (uint32_t)__popcll(m[u]);
         }
       }
@@ -665,7 +788,7 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
 // lane whose ray can touch a group puts (lane, group) on the wave's list, and
 // filter_listed_pairs does the rest.  `uncullable` lanes (rays outside the
 // range the boxes are valid for) list every group; lanes without a ray none.
-template <bool kCull, bool kCut = false>
+template <bool kCull, bool kCut = false, bool kInPlace = false>
 __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
                                            const FilterRayP &fr, const BoxRayP &br, bool alive, bool uncullable,
                                            WaveScan &w, HitState &h, float cut = 0.0f) {
@@ -673,13 +796,13 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
   if (!kCull) {
     ChunkRegs ra, rb;
-    load_chunk(ra, lds_pairs, 0);
+    load_chunk<kInPlace>(ra, lds_pairs, 0);
     for (uint32_t i0 = 0; i0 < count; i0 += kDrainEvery) {
-      load_chunk(rb, lds_pairs, i0 + kChunk);
+      load_chunk<kInPlace>(rb, lds_pairs, i0 + kChunk);
       if (w.wcnt > kWaveListFlushFull) drain_wave(sc, w, h);   // rare: the list usually lasts the whole scan
       filter_chunk(ra, base + i0, fr, w);
       // the read past the end of the last round stays inside the image and is never used
-      load_chunk(ra, lds_pairs, i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u);
+      load_chunk<kInPlace>(ra, lds_pairs, i0 + kDrainEvery < count ? i0 + kDrainEvery : 0u);
       if (w.wcnt > kWaveListFlushFull) drain_wave(sc, w, h);
       filter_chunk(rb, base + i0 + kChunk, fr, w);
     }
@@ -696,6 +819,9 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
       asm("" : "+s"(tail), "+s"(field));   // keep each one scalar operand
       lds_u16 *dst = (lds_u16 *)(uintptr_t)(tail + (rank << 1));
       if (mine) *dst = (uint16_t)(field | w.lane);
+#if RT_EXP == 56
+      if (mine) lds_again_write_b16(tail + (rank << 1), field | w.lane);
+#endif
       w.pcnt += (uint32_t)__popcll(m);
     }
   };
@@ -717,7 +843,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
         h.fill[4] += (uint32_t)__popcll(own_mask);
         h.fill[5] += 1u;
 #endif
-        const float4 *src = lds_pairs + g * kChunk + 4u * half;
+        const float4 *src = lds_pairs + pair_slot<kInPlace>(g * kChunk) + 4u * half;
         const float4 q[4] = {src[0], src[1], src[2], src[3]};
         f32x2 d[2];
         filter_two_pairs(fr, q, d[0], d[1]);
@@ -735,6 +861,9 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
               asm("" : "+s"(pos), "+s"(tail));   // keep each one scalar operand
               lds_u32 *dst = (lds_u32 *)(uintptr_t)(tail + (rank << 2));
               if (d[u >> 1][u & 1] > 0.0f && own) *dst = w.lane16 | pos;
+#if RT_EXP == 57
+              if (d[u >> 1][u & 1] > 0.0f && own) lds_again_write_b32(tail + (rank << 2), w.lane16 | pos);
+#endif
               w.wcnt += (uint32_t)__popcll(m[u]);
             }
           }
@@ -832,7 +961,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
       h.own_groups += (mine0 ? 1u : 0u) + (mine1 ? 1u : 0u);
       h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
       if (w.pcnt > kPairListFlush) {
-        filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);
+        filter_listed_pairs<kInPlace>(sc, lds_pairs, lds.real8, base, w, h);
         load_round(ahead, ahead_first);
       }
       list_group(m0, mine0, i0 >> 3);
@@ -856,15 +985,15 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     }
   }
   RT_HSTAGE_END(37);
-  filter_listed_pairs(sc, lds_pairs, lds.real8, base, w, h);   // (the pairs name groups of this batch)
+  filter_listed_pairs<kInPlace>(sc, lds_pairs, lds.real8, base, w, h);   // (the pairs name groups of this batch)
   h.box_tests += tests;
 }
 
 // Closest hit of the ray (A, B) of every lane of the workgroup against the
 // whole scene, within (tmin, tmax).  Unbatched: the scene is already resident
-// in LDS.  Batched: it is streamed through LDS in kBatchSpheres pieces, which
-// needs every wave of the workgroup here together.  Lanes without a ray pass
-// dead_ray().
+// in LDS.  Batched: it is scanned in place from global memory in pieces of
+// kBatchSpheres scan positions, every wave on its own (nothing is staged and
+// there is no barrier).  Lanes without a ray pass dead_ray().
 template <bool kBatched, bool kCull, bool kProfile = false>
 __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const ScanLds &lds, uint32_t tid, bool alive,
                                                   V3 A, V3 B, float tmin, float tmax, HitState &h) {
@@ -876,12 +1005,13 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   // rays outside the range the group boxes were derived for scan every group
   const bool uncullable = kCull && alive && !box_ray_in_range(A, B);
   const uint32_t wave_first = tid & ~63u;
+  static_assert(kRayRows * 64u * sizeof(float2) == 64u * 48u, "48 bytes of ray table per lane (scan_lds_bytes)");
   WaveScan w;
   w.wlist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
       (int)(uint32_t)(uintptr_t)(lds_u32 *)(lds.wlist + (tid >> 6) * wave_list_cap(kCull)));
   w.plist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
       (int)(uint32_t)(uintptr_t)(lds_u16 *)(lds.plist + (tid >> 6) * kPairListCap));
-  w.rays = lds.rays + 3 * wave_first;
+  w.rays_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32 *)(lds.rays + kRayRows * wave_first));
   w.best = lds.best + wave_first;
   w.wcnt = 0;
   w.pcnt = 0;
@@ -891,15 +1021,35 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   // this lane's ray and "no hit yet" key where the other lanes of the wave can reach them; the
   // key {tmax bits, 0} can only be undercut by t < tmax
   const double inv_a = reciprocal_of_widened_float((double)a);   // one reciprocal per ray, no division per sphere
-  lds.rays[3 * tid] = make_float4(A.x, A.y, A.z, a);
-  lds.rays[3 * tid + 1] = make_float4(B.x, B.y, B.z, f.na);
-  lds.rays[3 * tid + 2] = make_float4(__int_as_float(__double2loint(inv_a)), __int_as_float(__double2hiint(inv_a)), f.ab, f.naaa);
+  {
+    float2 *mine = lds.rays + kRayRows * wave_first + (tid & 63u);
+    mine[0] = make_float2(A.x, A.y);
+    mine[64] = make_float2(A.z, a);
+    mine[128] = make_float2(B.x, B.y);
+    mine[192] = make_float2(B.z, f.na);
+    mine[256] = make_float2(__int_as_float(__double2loint(inv_a)), __int_as_float(__double2hiint(inv_a)));
+    mine[320] = make_float2(f.ab, f.naaa);
+#if RT_EXP == 58
+    auto again = [&](uint32_t row, float lo, float hi) {
+      lds_again_write_b64(lds_address(mine + 64u * row), ((unsigned long long)__float_as_uint(hi) << 32) | __float_as_uint(lo));
+    };
+    again(0, A.x, A.y);
+    again(1, A.z, a);
+    again(2, B.x, B.y);
+    again(3, B.z, f.na);
+    again(4, __int_as_float(__double2loint(inv_a)), __int_as_float(__double2hiint(inv_a)));
+    again(5, f.ab, f.naaa);
+#endif
+  }
   {
     // (made here on every call: as a loop invariant the 64-bit constant would sit in two vector
     // registers for the whole kernel)
     uint32_t no_hit_hi = __float_as_uint(tmax), no_hit_lo = 0u;
     asm volatile("" : "+v"(no_hit_hi), "+v"(no_hit_lo));
     lds.best[tid] = ((unsigned long long)no_hit_hi << 32) | no_hit_lo;
+#if RT_EXP == 58
+    lds_again_write_b64(lds_address(&lds.best[tid]), ((unsigned long long)no_hit_hi << 32) | no_hit_lo);
+#endif
   }
   RT_HSTAGE_END(35);
   if (kBatched) {
@@ -974,7 +1124,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       in_place.sboxes = const_cast<float4 *>(sc.sboxes + 3u * (base / 64u));
       in_place.qboxes = const_cast<float4 *>(sc.qboxes + 3u * (base / 256u));
       in_place.real8 = const_cast<uint8_t *>(sc.group_real + base / 8u);
-      scan_batch<kCull, kCull>(sc, in_place, base, span, fr, br, alive, uncullable, w, h, cut);
+      scan_batch<kCull, kCull, true>(sc, in_place, base, span, fr, br, alive, uncullable, w, h, cut);
     };
     if (kCull && live_mask != 0ull) {
       // Near batches first, and every hit found narrows what is still worth a visit (rtcore: distance cut).
@@ -1123,9 +1273,11 @@ struct TraceArgs {
   Camera cam;
   PathGeom geo;
   DeviceScene sc;
-  float4 *rad;            // [SB][rows*nx] {r, g, b, first-hit index bits}
+  float4 *rad;            // [SB][rows*nx] {r, g, b, first-hit index bits}, or, when rad_words is 3, {r, g, b} packed
   unsigned int *queue;    // next unclaimed id (two words are kept per buffer; the second is unused)
   unsigned long long *counters;
+  uint32_t rad_words;     // 4, or 3 when the caller wants neither first_hit nor hit_sum: the fourth word of a path's
+                          // record is then neither written nor read (a quarter of the kernel's HBM traffic)
 };
 
 // A member of the kernel's argument struct, read from the kernel-argument segment at the point of use
@@ -1145,6 +1297,16 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
 #pragma unroll
   for (int q = 0; q < (int)(sizeof(T) / 4); ++q) dst[q] = src[q];
   return out;
+}
+
+// a finished path's record into the radiance buffer (the pointer and the record size come from the kernel-argument
+// segment at this point; the size is the same for every wave of a launch)
+__device__ __forceinline__ void store_radiance(uint32_t out_index, V3 color, int32_t first_hit) {
+  float *rad = reinterpret_cast<float *>(kernarg_now<float4 *>(offsetof(TraceArgs, rad)));
+  if (kernarg_now<uint32_t>(offsetof(TraceArgs, rad_words)) == 3u)
+    *reinterpret_cast<float3 *>(rad + (size_t)3 * out_index) = make_float3(color.x, color.y, color.z);
+  else
+    *reinterpret_cast<float4 *>(rad + (size_t)4 * out_index) = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
 }
 
 // kProfile: also accumulate, per wave, the shader cycles spent in the scan, the
@@ -1296,7 +1458,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
           done = true;
         }
         if (done) {
-          kernarg_now<float4 *>(offsetof(TraceArgs, rad))[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
+          store_radiance(out_index, color, first_hit);
           finished = true;
           alive = false;
         }
@@ -1415,7 +1577,7 @@ __global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void t
       depth++;
       done = done || depth >= job.max_depth;                  // c/main.c:262, 282
       if (done) {
-        kernarg_now<float4 *>(offsetof(TraceArgs, rad))[out_index] = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
+        store_radiance(out_index, color, first_hit);
         finished = true;
         alive = false;
       }
@@ -1486,6 +1648,7 @@ struct ResolveArgs {
   const float4 *rad;
   float4 *acc;
   int32_t *fh_acc;        // first-hit index of sample 0, carried across batches
+  uint32_t rad_words;     // 4, or 3: records without the first-hit word (first_hit and hit_sum are then not produced)
   uint32_t npix, batch, nsamples;   // nsamples: all samples the sums will hold after this batch's launch sequence
   int first_batch, last_batch;
   int keep_sum;           // also store the sums on the last batch (RT_FLAG_PROGRESSIVE)
@@ -1505,12 +1668,20 @@ __device__ __forceinline__ void resolve_pixel(const ResolveArgs &args, uint32_t 
     hsum = (uint32_t)__float_as_int(a.w);
     fh0 = args.fh_acc[p];
   }
-  for (uint32_t s = 0; s < args.batch; ++s) {
-    float4 v = args.rad[(size_t)s * args.npix + p];
-    sum = sum + v3(v.x, v.y, v.z);               // c/main.c:468, in sample order
-    int32_t fh = __float_as_int(v.w);
-    hsum += (uint32_t)(fh + 1);
-    if (args.first_batch && s == 0) fh0 = fh;
+  if (args.rad_words == 3u) {
+    const float *rad3 = reinterpret_cast<const float *>(args.rad);
+    for (uint32_t s = 0; s < args.batch; ++s) {
+      const float3 v = *reinterpret_cast<const float3 *>(rad3 + 3 * ((size_t)s * args.npix + p));
+      sum = sum + v3(v.x, v.y, v.z);             // c/main.c:468, in sample order
+    }
+  } else {
+    for (uint32_t s = 0; s < args.batch; ++s) {
+      float4 v = args.rad[(size_t)s * args.npix + p];
+      sum = sum + v3(v.x, v.y, v.z);             // c/main.c:468, in sample order
+      int32_t fh = __float_as_int(v.w);
+      hsum += (uint32_t)(fh + 1);
+      if (args.first_batch && s == 0) fh0 = fh;
+    }
   }
   if (!args.last_batch || args.keep_sum) {
     args.acc[p] = make_float4(sum.x, sum.y, sum.z, __int_as_float((int)hsum));
@@ -1782,13 +1953,13 @@ __global__ __launch_bounds__(kBlockThreads) void debug_filter_kernel(const float
   const FilterRay f = make_filter_ray(A, B);
   const FilterRayP fr = pack_ray(f);
   // what closest_hit_scene keeps in the ray table, and what filter_listed_pairs makes of it
-  const float4 ra = make_float4(A.x, A.y, A.z, dot(B, B)), rb = make_float4(B.x, B.y, B.z, f.na), rc = make_float4(0.0f, 0.0f, f.ab, f.naaa);
+  const rt_v2f r0 = {A.x, A.y}, r1 = {A.z, dot(B, B)}, r2 = {B.x, B.y}, r3 = {B.z, f.na}, r5 = {f.ab, f.naaa};
   FilterRayP f2;
-  f2.p0 = f32x2{-rb.x, -rb.y};
-  f2.p1 = f32x2{-rb.z, rc.z};
-  f2.p2 = f32x2{-2.0f * ra.x, -2.0f * ra.y};
-  f2.p3 = f32x2{-2.0f * ra.z, rb.w};
-  f2.p4 = f32x2{rc.w, 0.0f};
+  f2.p0 = f32x2{-r2[0], -r2[1]};
+  f2.p1 = f32x2{-r3[0], r5[0]};
+  f2.p2 = f32x2{-2.0f * r0[0], -2.0f * r0[1]};
+  f2.p3 = f32x2{-2.0f * r1[0], r3[1]};
+  f2.p4 = f32x2{r5[1], 0.0f};
   for (uint32_t g = 0; g < n_spheres; g += kChunk) {
     float4 q[kChunk];
 #pragma unroll
@@ -2012,7 +2183,7 @@ DeviceScene scene_view(const rt_ctx *c) {
 }
 
 size_t scan_lds_bytes(uint32_t entries, bool cull) {
-  return (size_t)entries * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u + quarter_pairs(entries)) * sizeof(float4) +  // pair image, boxes
+  return (size_t)pair_image_entries(entries) * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u + quarter_pairs(entries)) * sizeof(float4) +  // pair image, boxes
          (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
          (size_t)(kBlockThreads / 64) * (wave_list_cap(cull) * sizeof(uint32_t) + kPairListCap * sizeof(uint16_t)) +  // wave lists
          (size_t)((entries / 8u + 15u) & ~15u);                                             // real spheres per group
@@ -2023,8 +2194,8 @@ size_t trace_lds_bytes(uint32_t n_pad, bool cull) { return scan_lds_bytes(n_pad 
 // kept under kRadBudgetBytes
 constexpr size_t kRadBudgetBytes = (size_t)3 << 30;
 
-uint32_t batch_size(uint32_t npix, uint32_t nsamples) {
-  size_t per_sample = (size_t)npix * sizeof(float4);
+uint32_t batch_size(uint32_t npix, uint32_t nsamples, uint32_t rad_words) {
+  size_t per_sample = (size_t)npix * rad_words * sizeof(float);
   size_t fit = kRadBudgetBytes / per_sample;
   if (fit < 1) fit = 1;
   return (uint32_t)(fit < nsamples ? fit : nsamples);
@@ -2080,6 +2251,7 @@ struct Workspace {
   unsigned int *queue;       // work-queue head of the trace kernel
   unsigned long long *counters;
   uint32_t batch;            // samples per launch
+  uint32_t rad_words;        // words per path in rad: 4, or 3 without the first-hit word (TraceArgs::rad_words)
 };
 
 // the persistent grid of a trace-kernel variant: as many workgroups as the device holds at the
@@ -2130,6 +2302,7 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Work
   t.rad = ws.rad[0];
   t.queue = ws.queue;
   t.counters = ws.counters;
+  t.rad_words = ws.rad_words;
   const bool cull_scan = (job->flags & RT_FLAG_FULL_SCAN) == 0;
   size_t lds = trace_lds_bytes(c->n_pad, cull_scan);
 #if RT_EXP >= 41 && RT_EXP <= 43   // occupancy experiment: an LDS request of which only three (41), four (42) or two (43) fit a CU
@@ -2203,6 +2376,7 @@ int launch_render(rt_ctx *c, const rt_camera *cam, const rt_job *job, const Work
     }
     ResolveArgs r;
     r.rad = ws.rad[buf];
+    r.rad_words = ws.rad_words;
     r.acc = ws.acc;
     r.fh_acc = ws.fh_acc;
     r.npix = npix;
@@ -2315,13 +2489,8 @@ int rt_ctx_create(int device, rt_ctx **out) {
   }
   c->stream = c->own_stream;
   // this device's copy of the static scratch (rt_render_device_static), with the device current
-  {
-    int rc_s = static_scratch_address(device, &c->static_scratch);
-    if (rc_s != RT_OK) {
-      rt_ctx_destroy(c);
-      return rc_s;
-    }
-  }
+  // (a context works without it: rt_render_device_static then returns an error, nothing else depends on it)
+  if (static_scratch_address(device, &c->static_scratch) != RT_OK) c->static_scratch = nullptr;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->num_cus = prop.multiProcessorCount;
@@ -2572,11 +2741,15 @@ int rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t
   RT_HIP(hipSetDevice(c->device));
   const uint32_t npix = rows * job->nx;
   Workspace ws;
-  ws.batch = batch_size(npix, job->nsamples);
+  // (the megakernel leaves the first-hit word of a path's record out when nobody will read it; the sums of a
+  // progressive render may be continued by a call that does)
+  ws.rad_words = (job->kernel == RT_KERNEL_MEGA && !progressive && !d_first_hit && !d_hit_sum) ? 3u : 4u;
+  ws.batch = batch_size(npix, job->nsamples, ws.rad_words);
+  const size_t rad_entries = ((size_t)ws.batch * npix * ws.rad_words + 3u) / 4u;   // in float4 units
   ws.pipelined = job->kernel == RT_KERNEL_MEGA && (job->flags & RT_FLAG_SERIAL) == 0;
-  if (ws.pipelined && (c->rad[0].cap < (size_t)ws.batch * npix || c->rad[1].cap < (size_t)ws.batch * npix))
+  if (ws.pipelined && (c->rad[0].cap < rad_entries || c->rad[1].cap < rad_entries))
     RT_HIP(hipStreamSynchronize(c->stream));   // (a buffer about to be replaced may still be in use)
-  if ((rc = c->rad[0].reserve((size_t)ws.batch * npix)) || (ws.pipelined && (rc = c->rad[1].reserve((size_t)ws.batch * npix)))) return rc;
+  if ((rc = c->rad[0].reserve(rad_entries)) || (ws.pipelined && (rc = c->rad[1].reserve(rad_entries)))) return rc;
   // (reserve keeps what a buffer holds unless it has to grow, and the sums of a progressive render were
   // reserved for the same npix)
   if ((ws.batch < job->nsamples || progressive) && ((rc = c->acc.reserve(npix)) || (rc = c->fh_acc.reserve(npix)))) return rc;
@@ -2607,6 +2780,8 @@ int rt_render_device_static(rt_ctx *c, const rt_camera *cam, const rt_job *job, 
   if (job->kernel != RT_KERNEL_MEGA) return fail(RT_ERR_LIMIT, "rt_render_device_static runs the megakernel only");
   if ((job->flags & RT_FLAG_PROGRESSIVE) != 0 || job->sample0 != 0)
     return fail(RT_ERR_LIMIT, "rt_render_device_static does not continue progressive renders");
+  // (the profiling kernel logs one word per wave behind the event counts; the scratch's header has no room for that)
+  if ((job->flags & RT_FLAG_PROFILE) != 0) return fail(RT_ERR_LIMIT, "rt_render_device_static does not run the profiling kernel");
   const uint64_t npix64 = (uint64_t)rt_job_rows(job) * job->nx;
   if (npix64 == 0) return fail(RT_ERR_ARG, "job covers no rows");
   if (npix64 > RT_STATIC_MAX_PIXELS)
@@ -2623,8 +2798,9 @@ int rt_render_device_static(rt_ctx *c, const rt_camera *cam, const rt_job *job, 
   unsigned char *base = c->static_scratch;
   const size_t acc_off = kHeader, fh_off = acc_off + (size_t)npix * sizeof(float4);
   const size_t rad_off = (fh_off + (size_t)npix * sizeof(int32_t) + 15u) & ~(size_t)15u;
-  const size_t fit = (RT_STATIC_SCRATCH_BYTES - rad_off) / ((size_t)npix * sizeof(float4));
   Workspace ws;
+  ws.rad_words = (!d_first_hit && !d_hit_sum) ? 3u : 4u;
+  const size_t fit = (RT_STATIC_SCRATCH_BYTES - rad_off) / ((size_t)npix * ws.rad_words * sizeof(float));
   ws.batch = (uint32_t)(fit < job->nsamples ? fit : job->nsamples);
   ws.queue = reinterpret_cast<unsigned int *>(base);
   ws.counters = reinterpret_cast<unsigned long long *>(base + 64);
@@ -2638,7 +2814,7 @@ int rt_render_device_static(rt_ctx *c, const rt_camera *cam, const rt_job *job, 
   RT_HIP(hipMemsetAsync(base, 0, kHeader, c->stream));
   // nothing below may create anything: the occupancy of the kernel variants was asked at scene upload
   const bool cull_scan = (job->flags & RT_FLAG_FULL_SCAN) == 0, batched = c->n_pad > kMaxLdsSpheres;
-  const void *fn = trace_kernel_fn(batched, cull_scan, (job->flags & RT_FLAG_PROFILE) != 0);
+  const void *fn = trace_kernel_fn(batched, cull_scan, false);
   if (c->blocks_per_cu.find(std::make_pair(fn, trace_lds_bytes(c->n_pad, cull_scan))) == c->blocks_per_cu.end())
     return fail(RT_ERR_HIP, "kernel occupancy unknown (scene upload did not complete)");
   return launch_render(c, cam, job, ws, false, d_rgb8, d_linear, d_first_hit, d_hit_sum);

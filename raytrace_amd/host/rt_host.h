@@ -94,7 +94,7 @@ void rth_set_error(const char *text);
  * of the one before (RT_FLAG_PROGRESSIVE), until target_samples are in the picture or a newer request
  * arrives.  After every pass the picture so far is published; rth_service_latest copies it out with its
  * request id and sample count.  rth_service_wait blocks until request `id` has reached min_samples (or
- * failed).  rth_service_stop joins the worker and frees everything. */
+ * its target_samples, if that is less; or failed).  rth_service_stop joins the worker and frees everything. */
 typedef struct rth_service rth_service;
 typedef struct {
   uint32_t nx, ny, pass_samples, target_samples, max_depth, seed;

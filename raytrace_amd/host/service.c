@@ -39,6 +39,7 @@ struct rth_service {
   /* outcome of the newest request the worker has taken up */
   uint64_t active_id;
   uint32_t active_samples;
+  uint32_t active_target;    /* samples that request ends at */
   int active_rc;
   char err[256];
   uint64_t uploads, passes;
@@ -59,6 +60,7 @@ static void *service_worker(void *arg) {
     s->pending_id = 0;
     s->active_id = id;
     s->active_samples = 0;
+    s->active_target = rq.target_samples;
     s->active_rc = RT_OK;
     pthread_mutex_unlock(&s->lock);
 
@@ -195,7 +197,8 @@ int rth_service_wait(rth_service *s, uint64_t id, uint32_t min_samples) {
   int rc = RT_OK;
   for (;;) {
     if (s->active_id == id && s->active_rc != RT_OK) { rc = s->active_rc; rth_set_error(s->err); break; }
-    if (s->active_id == id && s->active_samples >= min_samples) break;
+    /* (a request ends at its target: asking for more samples than that waits for its last pass) */
+    if (s->active_id == id && s->active_samples >= (min_samples < s->active_target ? min_samples : s->active_target)) break;
     if (s->active_id > id || (s->pending_id > id)) { rc = RT_ERR_ARG; rth_set_error("the request was superseded by a newer one"); break; }
     if (s->stop) { rc = RT_ERR_ARG; rth_set_error("the service is stopping"); break; }
     pthread_cond_wait(&s->published, &s->lock);

@@ -16,10 +16,15 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(world, argv, env_extra=None, timeout=None):
+KILL_AFTER_S = 5.0     # a rank that has not gone this long after SIGTERM gets SIGKILL
+
+
+def launch_ranks(world, argv, env_extra=None, timeout=None, kill_after=KILL_AFTER_S):
     """Runs `argv` (a command line, list of str) once per rank.  Rank 0 inherits stdout; every rank inherits
     stderr.  Returns 0, or the exit code of the first rank seen to fail; when a rank fails the others are
-    terminated (by pid) and their exit codes ignored."""
+    terminated (by pid) and their exit codes ignored.  A rank stuck inside a GPU or collective call does not act on
+    SIGTERM: whatever is still alive `kill_after` seconds after the terminate is killed (by pid), so the caller
+    always gets its answer."""
     port = free_port()
     procs = []
     for rank in range(world):
@@ -33,6 +38,8 @@ def launch_ranks(world, argv, env_extra=None, timeout=None):
         procs.append(subprocess.Popen(list(argv), env=env, stdout=out))
     t0 = time.monotonic()
     failed = 0
+    terminated_at = None
+    killed = False
     live = set(range(world))
     while live:
         for r in sorted(live):
@@ -44,10 +51,16 @@ def launch_ranks(world, argv, env_extra=None, timeout=None):
                 failed = rc if rc > 0 else 128 - rc
                 for q in live:                      # a rank failed: the others would wait for it for ever
                     procs[q].terminate()
+                terminated_at = time.monotonic()
         if live and failed == 0 and timeout is not None and time.monotonic() - t0 > timeout:
             failed = 124
             for q in live:
                 procs[q].terminate()
+            terminated_at = time.monotonic()
+        if live and terminated_at is not None and not killed and time.monotonic() - terminated_at > kill_after:
+            for q in live:
+                procs[q].kill()
+            killed = True
         if live:
             time.sleep(0.05)
     return failed

@@ -31,9 +31,10 @@ def oracle_rows(oracle, cam, osc, nx, ny, spp, seed, row_list, max_depth=50):
 
 @pytest.mark.parametrize("flags", [0, 2])
 def test_dense_field_render_equals_oracle(renderer, rt, oracle, flags):
-    """Baseline config 4: the 200x200 field, 40,004 spheres, streamed through LDS in 79 batches of 512 (so the
-    workgroup's batch mask uses both of its 64-bit halves), rendered by the trace kernel proper: culled
-    (batch boxes voted per workgroup) and with every sphere filtered for every ray."""
+    """Baseline config 4: the 200x200 field, 40,004 spheres, scanned in place from global memory in 79 batches of 512
+    scan positions (so a wave's batch mask uses both of its 64-bit halves), rendered by the trace kernel proper:
+    culled (region and batch boxes voted per wave, batches visited near to far under the distance cut) and with
+    every sphere filtered for every ray."""
     sc = rt.random_scene(100)
     assert len(sc) == 40004
     renderer.upload(sc)

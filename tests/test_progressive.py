@@ -80,7 +80,7 @@ def test_service_rerenders_on_a_new_camera_without_another_upload(rt, oracle):
         svc.wait(rid_b, 5)
         mid = svc.latest(nx, ny)
         assert mid["id"] == rid_b and mid["samples"] in (5, 10)
-        svc.wait(rid_b, 10)
+        svc.wait(rid_b, 1000)     # (more than the request's target: returns when the target is reached)
         got_b = svc.latest(nx, ny)
         want_b = oracle.render_det(cam_b.as_array(), as_oracle_scene(sc), nx, ny, 10, seed=3, host_threads=16, want_debug=False)
         assert got_b["samples"] == 10 and np.array_equal(got_b["rgb8"], want_b["rgb8"])

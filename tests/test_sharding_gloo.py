@@ -88,6 +88,18 @@ def test_self_launched_ranks_shard_and_gather(tmp_path, oracle, world):
     assert _launcher().launch_ranks(2, cmd, env_extra={"RT_TEST_FAIL_RANK": "1"}, timeout=300) == 3
 
 
+def test_a_rank_that_ignores_sigterm_is_killed():
+    """One rank fails at once, the other ignores SIGTERM and sleeps (a rank stuck inside a GPU or collective call
+    behaves like that): the launcher kills it by pid after its grace period and returns the failing rank's code."""
+    import time
+    code = ("import os, signal, sys, time\n"
+            "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+            "sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(120)\n")
+    t0 = time.monotonic()
+    rc = _launcher().launch_ranks(2, [sys.executable, "-c", code], timeout=60, kill_after=1.0)
+    assert rc == 7 and time.monotonic() - t0 < 30
+
+
 def test_bench_parent_spawns_before_touching_a_gpu():
     """The self-launch branch of bench.py runs before torch or the library is imported."""
     src = open(os.path.join(ROOT, "bench.py")).read()

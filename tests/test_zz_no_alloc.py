@@ -49,6 +49,10 @@ def test_static_entry_point_matches_the_allocating_one(rt):
             r.render_device(rt.camera_default(64, 36), rt.Job(64, 36, 1, kernel=rt.KERNEL_WAVEFRONT), out.data_ptr(), static=True)
         with pytest.raises(rt.RtError):
             r.render_device(rt.camera_default(64, 36), rt.Job(64, 36, 1, flags=rt.FLAG_PROGRESSIVE), out.data_ptr(), static=True)
+        # (the profiling kernel logs a word per wave behind the event counts: the scratch's header has no room for it)
+        with pytest.raises(rt.RtError) as e:
+            r.render_device(rt.camera_default(64, 36), rt.Job(64, 36, 1, flags=rt.FLAG_PROFILE), out.data_ptr(), static=True)
+        assert e.value.code == 5
         # and a frame too large for one call goes through in row bands
         nx, ny, spp = 1920, 1080, 2
         cam = rt.camera_default(nx, ny)
@@ -60,4 +64,53 @@ def test_static_entry_point_matches_the_allocating_one(rt):
         r.synchronize()
         assert torch.equal(whole, bands)
     finally:
+        r.close()
+
+
+def test_static_entry_point_allocates_nothing_and_runs_under_graph_capture(rt):
+    """The claim itself: device memory in use does not move across static calls, and a static call can be recorded into
+    a HIP graph (capture forbids allocation and synchronisation) whose replays give the allocating entry point's bytes.
+    Also with RT_FLAG_FULL_SCAN (another kernel instantiation) and with several sample batches."""
+    import torch
+    dev = torch.device("cuda", 0)
+    r = rt.Renderer(0)
+    stream = torch.cuda.Stream(dev)
+    try:
+        r.set_stream(stream.cuda_stream)
+        r.upload(rt.random_scene())
+        nx, ny = 320, 180
+        cam = rt.camera_default(nx, ny)
+        for flags, spp in ((0, 6), (rt.FLAG_FULL_SCAN, 3), (0, 160)):      # 160 spp: 147 MB of radiance, five batches
+            job = rt.Job(nx, ny, spp, seed=11, flags=flags)
+            want = torch.zeros((ny, nx, 3), dtype=torch.uint8, device=dev)
+            want_lin = torch.zeros((ny, nx, 3), dtype=torch.float32, device=dev)
+            r.render_device(cam, job, want.data_ptr(), want_lin.data_ptr())
+            got = torch.zeros_like(want)
+            got_lin = torch.zeros_like(want_lin)
+            r.render_device(cam, job, got.data_ptr(), got_lin.data_ptr(), static=True)      # warm-up of the static path
+            r.synchronize()
+            assert torch.equal(got, want) and torch.equal(got_lin.view(torch.int32), want_lin.view(torch.int32))
+            free_before, _ = torch.cuda.mem_get_info(dev)
+            for _ in range(3):
+                got.zero_()
+                r.render_device(cam, job, got.data_ptr(), got_lin.data_ptr(), static=True)
+            r.synchronize()
+            free_after, _ = torch.cuda.mem_get_info(dev)
+            assert free_after == free_before, "device memory moved across static calls"
+            assert torch.equal(got, want)
+            # recorded into a graph and replayed
+            got.zero_()
+            got_lin.zero_()
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                r.render_device(cam, job, got.data_ptr(), got_lin.data_ptr(), static=True)
+            for _ in range(2):
+                got.zero_()
+                graph.replay()
+                torch.cuda.synchronize(dev)
+                assert torch.equal(got, want) and torch.equal(got_lin.view(torch.int32), want_lin.view(torch.int32))
+            del graph
+    finally:
+        r.set_stream(0)
         r.close()
