@@ -435,6 +435,8 @@ def main():
                 "kernel": "trace_kernel" if args.kernel == "mega" else "wavefront stages",
                 "kernel_ms_avg": k_ms, "kernel_ms_steps_averaged": len(kernel_ms), "serial_leg_ms_per_step": sdt / serial_steps * 1e3,
                 "kernel_ms_bracketed_in_pipeline": float(np.mean(bracketed_ms)), "pipelined_step_ms_rank0": step_ms_rank,
+                "pipelined_step_ms_min_median_max": ([float(np.min(spacing_ms)), float(np.median(spacing_ms)), float(np.max(spacing_ms))]
+                                                     if spacing_ms else None),
                 "flop_per_test": FLOP_PER_TEST,
                 "sphere_tests_per_launch": sphere_per_launch, "box_tests_per_launch": box_per_launch,
                 "sphere_tests_per_path": serial_counters["sphere_tests"] / max(1, serial_counters["paths"]),

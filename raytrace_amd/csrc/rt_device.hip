@@ -30,6 +30,7 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -1315,8 +1316,11 @@ __device__ __forceinline__ void store_radiance(uint32_t out_index, V3 color, int
 // (second launch-bound argument: waves per SIMD.  The culled scan of an LDS-resident scene fits 96 VGPRs
 // and, with its short lists, 32,000 bytes of LDS, so five workgroups share a CU; the other variants keep
 // four, i.e. at most 128 VGPRs.)
+#ifndef RT_BATCHED_WAVES
+#define RT_BATCHED_WAVES 4      // waves per SIMD the culled scan of a scene scanned in place is compiled for
+#endif
 template <bool kBatched, bool kCull, bool kProfile>
-__global__ __launch_bounds__(kBlockThreads, (kCull && !kBatched) ? 5 : 4) void trace_kernel(const TraceArgs args) {
+__global__ __launch_bounds__(kBlockThreads, kCull ? (kBatched ? RT_BATCHED_WAVES : 5) : 4) void trace_kernel(const TraceArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DeviceScene &sc = args.sc;
   const rt_job &job = args.geo.job;
@@ -2744,6 +2748,10 @@ int rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t
   // (the megakernel leaves the first-hit word of a path's record out when nobody will read it; the sums of a
   // progressive render may be continued by a call that does)
   ws.rad_words = (job->kernel == RT_KERNEL_MEGA && !progressive && !d_first_hit && !d_hit_sum) ? 3u : 4u;
+  {
+    static const char *force = std::getenv("RT_EXP_RAD_WORDS");   // experiment hook: "4" keeps the 16-byte records
+    if (force && force[0] == '4') ws.rad_words = 4u;
+  }
   ws.batch = batch_size(npix, job->nsamples, ws.rad_words);
   const size_t rad_entries = ((size_t)ws.batch * npix * ws.rad_words + 3u) / 4u;   // in float4 units
   ws.pipelined = job->kernel == RT_KERNEL_MEGA && (job->flags & RT_FLAG_SERIAL) == 0;
