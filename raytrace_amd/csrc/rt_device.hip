@@ -67,7 +67,8 @@ using namespace rtcore;
 
 // RT_EXP 35..38: the profiling build's "drain" column shows one stage of the scan instead (35 ray set-up,
 // 36 super-group boxes, 37 group-box rounds without the filter passes they trigger, 38 filter passes)
-#define RT_SCAN_STAGE (RT_EXP >= 35 && RT_EXP <= 38)
+// RT_EXP 40: ... or, for a scene scanned in place, choosing the batches: region and batch boxes, near-to-far picks
+#define RT_SCAN_STAGE ((RT_EXP >= 35 && RT_EXP <= 38) || RT_EXP == 40)
 #define RT_HSTAGE_BEGIN(N) const unsigned long long hstage_t0_##N = (RT_EXP == N) ? tick() : 0ull
 #define RT_HSTAGE_END(N) \
   do {                   \
@@ -255,6 +256,17 @@ constexpr uint32_t kPairListCap = 280;              // (lane, group) entries per
                                                     // 512-position scene: five fit a CU's 160 KiB, which is handed out
                                                     // in 1280-byte units)
 constexpr uint32_t kPairListFlush = kPairListCap - 2u * 64u;       // a round adds at most two groups for 64 lanes
+// A scene scanned in place, between two batches: the listed (lane, group) pairs are filtered once there are this many (a
+// pass takes 64; dense field: 3.65e9 paths/s against 3.54e9 with a pass after every batch, 32 .. 64 within 1 %), the
+// candidates are evaluated after every batch that produced any -- holding them back as well costs more in boxes the
+// later cuts would have ruled out than the fuller passes save (40 / 40: 3.48e9).
+#ifndef RT_MERGE_PAIRS
+#define RT_MERGE_PAIRS 40
+#endif
+#ifndef RT_MERGE_CANDIDATES
+#define RT_MERGE_CANDIDATES 1
+#endif
+constexpr uint32_t kMergePairs = RT_MERGE_PAIRS, kMergeCandidates = RT_MERGE_CANDIDATES;
 
 // The per-lane ray table.  Any lane of a wave reads any other lane's ray from it (the lists name an owner), so
 // what matters is how 32 or 16 arbitrary owners fall on the LDS banks.  Eight-byte entries, 64 owners to a row of
@@ -275,7 +287,9 @@ struct ScanLds {
                                  // {A.B, naaa of the filter}
   unsigned long long *best;      // 1 per lane
   uint32_t *wlist;               // wave_list_cap() per wave: (owner lane << 16) | scan position
-  uint16_t *plist;               // kPairListCap per wave: (group within the batch << 6) | owner lane
+  uint16_t *plist;               // kPairListCap entries per wave: (group << 6) | owner lane -- 16 bits each for a scene
+                                 // resident in LDS, 32 bits each (the group counted from the start of the scan order) for
+                                 // one scanned in place
   uint8_t *real8;                // per group of the batch: its real (non-pad) spheres
 };
 
@@ -300,7 +314,7 @@ __device__ __forceinline__ ScanLds carve_lds(unsigned char *smem, uint32_t entri
   l.best = reinterpret_cast<unsigned long long *>(l.rays + kRayRows * kBlockThreads);
   l.wlist = reinterpret_cast<uint32_t *>(l.best + kBlockThreads);
   l.plist = reinterpret_cast<uint16_t *>(l.wlist + (kBlockThreads / 64) * wave_list_cap(kCull));
-  l.real8 = reinterpret_cast<uint8_t *>(l.plist + (kBlockThreads / 64) * kPairListCap);
+  l.real8 = reinterpret_cast<uint8_t *>(l.plist + (kBlockThreads / 64) * kPairListCap * (entries == 0u ? 2u : 1u));
   return l;
 }
 
@@ -679,12 +693,14 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
   for (uint32_t e0 = 0; e0 < w.pcnt;) {
     const uint32_t e = e0 + w.lane;
     const bool valid = w.lane < width && e < w.pcnt;
-    const uint32_t entry = valid ? (uint32_t)*(lds_u16 *)(uintptr_t)(w.plist_off + (e << 1)) : 0u;
+    const uint32_t entry = !valid ? 0u
+                           : kInPlace ? *(lds_u32 *)(uintptr_t)(w.plist_off + (e << 2))
+                                      : (uint32_t)*(lds_u16 *)(uintptr_t)(w.plist_off + (e << 1));
     const uint32_t owner = entry & 63u, grp = entry >> 6;
     rt_v2f r0, r1, r2, r3, r5;
     ray_table_read5<0, 1, 2, 3, 5>(w.rays_off + (owner << 3), r0, r1, r2, r3, r5);
 #if RT_EXP == 55
-    if (valid) lds_again_read_u16(w.plist_off + (e << 1));
+    if (valid && !kInPlace) lds_again_read_u16(w.plist_off + (e << 1));
 #endif
 #if RT_EXP == 51
     {
@@ -816,13 +832,21 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     if (m != 0ull) {
       asm volatile("");
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      uint32_t tail = w.plist_off + (w.pcnt << 1), field = grp << 6;
-      asm("" : "+s"(tail), "+s"(field));   // keep each one scalar operand
-      lds_u16 *dst = (lds_u16 *)(uintptr_t)(tail + (rank << 1));
-      if (mine) *dst = (uint16_t)(field | w.lane);
+      if (kInPlace) {
+        // (the list outlives the batch: the group is counted from the start of the scan order)
+        uint32_t tail = w.plist_off + (w.pcnt << 2), field = (base / (uint32_t)kChunk + grp) << 6;
+        asm("" : "+s"(tail), "+s"(field));   // keep each one scalar operand
+        lds_u32 *dst = (lds_u32 *)(uintptr_t)(tail + (rank << 2));
+        if (mine) *dst = field | w.lane;
+      } else {
+        uint32_t tail = w.plist_off + (w.pcnt << 1), field = grp << 6;
+        asm("" : "+s"(tail), "+s"(field));   // keep each one scalar operand
+        lds_u16 *dst = (lds_u16 *)(uintptr_t)(tail + (rank << 1));
+        if (mine) *dst = (uint16_t)(field | w.lane);
 #if RT_EXP == 56
-      if (mine) lds_again_write_b16(tail + (rank << 1), field | w.lane);
+        if (mine) lds_again_write_b16(tail + (rank << 1), field | w.lane);
 #endif
+      }
       w.pcnt += (uint32_t)__popcll(m);
     }
   };
@@ -962,7 +986,7 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
       h.own_groups += (mine0 ? 1u : 0u) + (mine1 ? 1u : 0u);
       h.wave_groups += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);
       if (w.pcnt > kPairListFlush) {
-        filter_listed_pairs<kInPlace>(sc, lds_pairs, lds.real8, base, w, h);
+        filter_listed_pairs<kInPlace>(sc, lds_pairs, lds.real8, kInPlace ? 0u : base, w, h);
         load_round(ahead, ahead_first);
       }
       list_group(m0, mine0, i0 >> 3);
@@ -986,7 +1010,9 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
     }
   }
   RT_HSTAGE_END(37);
-  filter_listed_pairs<kInPlace>(sc, lds_pairs, lds.real8, base, w, h);   // (the pairs name groups of this batch)
+  // (a scene in LDS: the pairs name groups of this one batch.  Scanned in place, the list goes on to the next batch
+  // and the caller decides when it is worth a pass: closest_hit_scene)
+  if (!kInPlace) filter_listed_pairs<false>(sc, lds_pairs, lds.real8, base, w, h);
   h.box_tests += tests;
 }
 
@@ -1011,7 +1037,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   w.wlist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
       (int)(uint32_t)(uintptr_t)(lds_u32 *)(lds.wlist + (tid >> 6) * wave_list_cap(kCull)));
   w.plist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
-      (int)(uint32_t)(uintptr_t)(lds_u16 *)(lds.plist + (tid >> 6) * kPairListCap));
+      (int)(uint32_t)(uintptr_t)(lds_u16 *)(lds.plist + (tid >> 6) * kPairListCap * (kBatched ? 2u : 1u)));
   w.rays_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32 *)(lds.rays + kRayRows * wave_first));
   w.best = lds.best + wave_first;
   w.wcnt = 0;
@@ -1071,6 +1097,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       return BoxPairS{f32x2{e[0], e[1]}, f32x2{e[2], e[3]}, f32x2{e[4], e[5]}, f32x2{e[6], e[7]}, f32x2{e[8], e[9]}, f32x2{e[10], e[11]}};
     };
     const unsigned long long all_mask = __ballot(uncullable), live_mask = __ballot(alive);
+    RT_HSTAGE_BEGIN(40);
     if (kCull) {
       const uint32_t n_batch_pairs = batch_pairs(sc.n_pad);
       unsigned long long mine_lo = 0ull, mine_hi = 0ull;
@@ -1120,11 +1147,13 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       // (without culling the trailing padding is not visited)
       const uint32_t span = kCull ? count : (sc.n_full > base ? min(count, sc.n_full - base) : 0u);
       ScanLds in_place = lds;   // (the per-wave lists, rays and keys stay in LDS; the scene's arrays are the global ones)
-      in_place.pairs = const_cast<float4 *>(sc.filter + base);
+      // (the culled scan's pair list names groups counted from the start of the scan order, so its pair image and
+      // group sizes are the whole arrays; the scan without culling walks the batch's own part)
+      in_place.pairs = const_cast<float4 *>(kCull ? sc.filter : sc.filter + base);
       in_place.boxes = const_cast<float4 *>(sc.boxes + 3u * (base / 16u));
       in_place.sboxes = const_cast<float4 *>(sc.sboxes + 3u * (base / 64u));
       in_place.qboxes = const_cast<float4 *>(sc.qboxes + 3u * (base / 256u));
-      in_place.real8 = const_cast<uint8_t *>(sc.group_real + base / 8u);
+      in_place.real8 = const_cast<uint8_t *>(kCull ? sc.group_real : sc.group_real + base / 8u);
       scan_batch<kCull, kCull, true>(sc, in_place, base, span, fr, br, alive, uncullable, w, h, cut);
     };
     if (kCull && live_mask != 0ull) {
@@ -1186,13 +1215,23 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
 #if RT_EXP == 39
         h.fill[6] += 1u;
 #endif
+        RT_HSTAGE_EXCLUDE_BEGIN(40);
         visit(base, cut);
-        if (w.wcnt != 0u) {
+        // What the visit listed is filtered at once after batch 0 (the ground sphere of scenes like the reference's
+        // lives there and its hit cuts most of what follows), afterwards only when a pass would run with enough of its
+        // lanes at work; the rest waits for the next batch's, or for the end of the scan.  Candidates are evaluated
+        // as soon as there are kMergeCandidates of them, and every evaluation moves the cuts up.
+        const bool at_once = bi == 0u;
+        if (w.pcnt != 0u && (at_once || w.pcnt >= kMergePairs)) filter_listed_pairs<true>(sc, sc.filter, sc.group_real, 0u, w, h);
+        if (w.wcnt != 0u && (at_once || w.wcnt >= kMergeCandidates)) {
           drain_wave(sc, w, h);
           const float t_best = __uint_as_float((uint32_t)(lds.best[tid] >> 32));
           cut = rt_fma(t_best, kCutRel, slack);
         }
+        RT_HSTAGE_EXCLUDE_END(40);
       }
+      RT_HSTAGE_END(40);
+      if (w.pcnt != 0u) filter_listed_pairs<true>(sc, sc.filter, sc.group_real, 0u, w, h);
     } else if (!kCull) {
 #pragma unroll 1
       for (uint32_t half = 0; half < 2u; ++half) {
@@ -2189,7 +2228,7 @@ DeviceScene scene_view(const rt_ctx *c) {
 size_t scan_lds_bytes(uint32_t entries, bool cull) {
   return (size_t)pair_image_entries(entries) * sizeof(float4) + (size_t)3 * (entries / 16u + entries / 64u + quarter_pairs(entries)) * sizeof(float4) +  // pair image, boxes
          (size_t)3 * kBlockThreads * sizeof(float4) + (size_t)kBlockThreads * sizeof(unsigned long long) +  // rays, keys
-         (size_t)(kBlockThreads / 64) * (wave_list_cap(cull) * sizeof(uint32_t) + kPairListCap * sizeof(uint16_t)) +  // wave lists
+         (size_t)(kBlockThreads / 64) * (wave_list_cap(cull) * sizeof(uint32_t) + kPairListCap * (entries == 0u ? sizeof(uint32_t) : sizeof(uint16_t))) +  // wave lists
          (size_t)((entries / 8u + 15u) & ~15u);                                             // real spheres per group
 }
 size_t trace_lds_bytes(uint32_t n_pad, bool cull) { return scan_lds_bytes(n_pad <= kMaxLdsSpheres ? n_pad : 0u, cull); }
