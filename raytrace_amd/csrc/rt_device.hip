@@ -1339,14 +1339,23 @@ __device__ __forceinline__ T kernarg_now(size_t offset) {
   return out;
 }
 
+// A pointer read with kernarg_now has lost its address space: the compiler would reach through it with flat
+// instructions, which also count as LDS traffic for the wave's wait counters.  These name global memory again.
+typedef float rt_vec4f __attribute__((ext_vector_type(4)));
+typedef float rt_vec3f __attribute__((ext_vector_type(3)));
+typedef __attribute__((address_space(1))) float global_f32;
+typedef __attribute__((address_space(1))) rt_vec4f global_vec4f;
+typedef __attribute__((address_space(1))) rt_vec3f global_vec3f;
+typedef __attribute__((address_space(1))) unsigned int global_u32;
+
 // a finished path's record into the radiance buffer (the pointer and the record size come from the kernel-argument
 // segment at this point; the size is the same for every wave of a launch)
 __device__ __forceinline__ void store_radiance(uint32_t out_index, V3 color, int32_t first_hit) {
-  float *rad = reinterpret_cast<float *>(kernarg_now<float4 *>(offsetof(TraceArgs, rad)));
+  global_f32 *rad = (global_f32 *)(uintptr_t)kernarg_now<float4 *>(offsetof(TraceArgs, rad));
   if (kernarg_now<uint32_t>(offsetof(TraceArgs, rad_words)) == 3u)
-    *reinterpret_cast<float3 *>(rad + (size_t)3 * out_index) = make_float3(color.x, color.y, color.z);
+    *(global_vec3f *)(rad + (size_t)3 * out_index) = rt_vec3f{color.x, color.y, color.z};
   else
-    *reinterpret_cast<float4 *>(rad + (size_t)4 * out_index) = make_float4(color.x, color.y, color.z, __int_as_float(first_hit));
+    *(global_vec4f *)(rad + (size_t)4 * out_index) = rt_vec4f{color.x, color.y, color.z, __int_as_float(first_hit)};
 }
 
 // kProfile: also accumulate, per wave, the shader cycles spent in the scan, the
@@ -1421,6 +1430,8 @@ __global__ __launch_bounds__(kBlockThreads, kCull ? (kBatched ? RT_BATCHED_WAVES
   for (;;) {
     unsigned long long c0 = 0, c1 = 0, c2 = 0;
     int pending = kNone;
+    // (read only where `pending` says they were set; left without initial values the kernel saves three dozen moves
+    // and then needs 22 registers more than its 96)
     V3 p = v3(0, 0, 0), n = v3(0, 0, 0), albedo = v3(0, 0, 0);   // (kNewPath: p.x, p.y hold the pixel's x, y)
     V3 unitB = v3(0, 0, 1);                                        // normalize(B) of the ray just traced
     float fuzz = 0.0f;
@@ -1475,10 +1486,11 @@ __global__ __launch_bounds__(kBlockThreads, kCull ? (kBatched ? RT_BATCHED_WAVES
         bool done = false;
         if (depth == 0) first_hit = h.index;
         if (h.index >= 0) {
-          const float4 *rec = kernarg_now<const float4 *>(offsetof(TraceArgs, sc) + offsetof(DeviceScene, shade_o)) + 3 * h.index;
-          const float4 e = rec[0];
-          const float4 m4 = rec[1];
-          const float4 tail = rec[2];
+          const global_vec4f *rec =
+              (const global_vec4f *)(uintptr_t)kernarg_now<const float4 *>(offsetof(TraceArgs, sc) + offsetof(DeviceScene, shade_o)) + 3 * h.index;
+          const rt_vec4f e = rec[0];
+          const rt_vec4f m4 = rec[1];
+          const rt_vec4f tail = rec[2];
           const int type = __float_as_int(tail.z);
           p = A + h.closest * B;                              // c/structs.c:6-8
           const double inv_r = __hiloint2double(__float_as_int(tail.y), __float_as_int(tail.x));
@@ -1517,7 +1529,9 @@ __global__ __launch_bounds__(kBlockThreads, kCull ? (kBatched ? RT_BATCHED_WAVES
       if (pool_next == pool_end) {
         uint32_t base = 0;
         const uint32_t limit = geo.total_items, take = geo.chunk;
-        if (lane == 0) base = atomicAdd(kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)), take);
+        if (lane == 0)
+          base = __hip_atomic_fetch_add((global_u32 *)(uintptr_t)kernarg_now<unsigned int *>(offsetof(TraceArgs, queue)), take, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= limit) {
           exhausted = true;
@@ -2517,8 +2531,19 @@ int rt_ctx_create(int device, rt_ctx **out) {
   if (!c) return fail(RT_ERR_NOMEM, "out of host memory");
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->trace_stream[0], hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->trace_stream[1], hipStreamNonBlocking);
+  {
+    // The two trace streams get the lowest stream priority.  Not for the scheduling: the runtime keeps a pool of
+    // hardware queues per priority, so streams of a priority nobody else uses never share a hardware queue with the
+    // caller's streams.  Sharing one is fatal for the overlap of consecutive launches: the wait "resolve after its
+    // trace" queued on the caller's stream sits in front of the NEXT trace launch in the same hardware queue, and
+    // every launch then starts only when the one before it has ended (measured with the process limited to two
+    // hardware queues: 12.3 ms per 1080p frame against 10.9; with the priority set, 10.9 either way; with the
+    // default four queues the sharing happens in some runs and not in others).
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->trace_stream[0], hipStreamNonBlocking, least);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->trace_stream[1], hipStreamNonBlocking, least);
+  }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) {
     e = hipEventCreateWithFlags(&c->ev_traced[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_resolved[i], hipEventDisableTiming);
