@@ -479,6 +479,9 @@ def main():
                                "kernel_ms_max_over_mean": max(ks) / (sum(ks) / len(ks)),
                                "pipelined_step_ms_max_over_mean": max(st) / (sum(st) / len(st))}
         if weak is not None:
+            weak["note"] = ("this leg renders the N = 1 line's workload (final1080, 64 spp per GPU): its value over the N = 1 line's value "
+                            "is the like-for-like scaling figure; `value` of this line is the fixed 3840x2160x1024 frame (strong scaling), "
+                            "a different workload from the N = 1 line's")
             out["weak_scaling"] = weak
         if linear is not None:
             out["linear_scan"] = linear
