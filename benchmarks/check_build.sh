@@ -1,3 +1,4 @@
+# GPU suite, bench lines of three workloads and the LDS attribution of one build:  benchmarks/check_build.sh <tag>
 set -u
 tag=${1:-r03_c}
 mkdir -p gpurun_out/$tag

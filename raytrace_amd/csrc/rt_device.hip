@@ -30,7 +30,6 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -2532,17 +2531,19 @@ int rt_ctx_create(int device, rt_ctx **out) {
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   {
-    // The two trace streams get the lowest stream priority.  Not for the scheduling: the runtime keeps a pool of
+    // The two trace streams get the highest stream priority.  Not for the scheduling: the runtime keeps a pool of
     // hardware queues per priority, so streams of a priority nobody else uses never share a hardware queue with the
     // caller's streams.  Sharing one is fatal for the overlap of consecutive launches: the wait "resolve after its
     // trace" queued on the caller's stream sits in front of the NEXT trace launch in the same hardware queue, and
     // every launch then starts only when the one before it has ended (measured with the process limited to two
     // hardware queues: 12.3 ms per 1080p frame against 10.9; with the priority set, 10.9 either way; with the
-    // default four queues the sharing happens in some runs and not in others).
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->trace_stream[0], hipStreamNonBlocking, least);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->trace_stream[1], hipStreamNonBlocking, least);
+    // default four queues the sharing happens in some runs and not in others).  The lowest priority gives the same
+    // separation but must not be used: when two processes share a GPU their normal-priority queues, waiting on
+    // events of the trace streams, keep the low-priority queues that would signal those events from ever running.
+    int least = 0, greatest = 0, chosen = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) chosen = greatest;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->trace_stream[0], hipStreamNonBlocking, chosen);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->trace_stream[1], hipStreamNonBlocking, chosen);
   }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) {
     e = hipEventCreateWithFlags(&c->ev_traced[i], hipEventDisableTiming);
@@ -2812,10 +2813,6 @@ int rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_job *job, uint8_t
   // (the megakernel leaves the first-hit word of a path's record out when nobody will read it; the sums of a
   // progressive render may be continued by a call that does)
   ws.rad_words = (job->kernel == RT_KERNEL_MEGA && !progressive && !d_first_hit && !d_hit_sum) ? 3u : 4u;
-  {
-    static const char *force = std::getenv("RT_EXP_RAD_WORDS");   // experiment hook: "4" keeps the 16-byte records
-    if (force && force[0] == '4') ws.rad_words = 4u;
-  }
   ws.batch = batch_size(npix, job->nsamples, ws.rad_words);
   const size_t rad_entries = ((size_t)ws.batch * npix * ws.rad_words + 3u) / 4u;   // in float4 units
   ws.pipelined = job->kernel == RT_KERNEL_MEGA && (job->flags & RT_FLAG_SERIAL) == 0;
