@@ -807,7 +807,7 @@ __device__ __forceinline__ void filter_listed_pairs(const DeviceScene &sc, const
 template <bool kCull, bool kCut = false, bool kInPlace = false>
 __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds &lds, uint32_t base, uint32_t count,
                                            const FilterRayP &fr, const BoxRayP &br, bool alive, bool uncullable,
-                                           WaveScan &w, HitState &h, float cut = 0.0f) {
+                                           WaveScan &w, HitState &h, float cut = 0.0f, bool first_direct = false) {
   const float4 *lds_pairs = lds.pairs, *lds_boxes = lds.boxes, *lds_sboxes = lds.sboxes;
   static_assert(kDrainEvery == 2 * kChunk, "two register sets per round");
   if (!kCull) {
@@ -874,6 +874,8 @@ __device__ __forceinline__ void scan_batch(const DeviceScene &sc, const ScanLds 
         unsigned long long m[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) m[u] = __ballot(d[u >> 1][u & 1] > 0.0f) & own_mask;
+        // (closest_hit_scene has evaluated the sphere at scan position 0 for every lane's own ray already)
+        if (first_direct && g == 0u && half == 0u) m[0] = 0ull;
         if (((m[0] | m[1]) | (m[2] | m[3])) != 0ull) {
           asm volatile("");
 #pragma unroll
@@ -1031,6 +1033,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   // rays outside the range the group boxes were derived for scan every group
   const bool uncullable = kCull && alive && !box_ray_in_range(A, B);
   const uint32_t wave_first = tid & ~63u;
+  const bool first_direct = kCull && sc.n_always_groups != 0u;
   static_assert(kRayRows * 64u * sizeof(float2) == 64u * 48u, "48 bytes of ray table per lane (scan_lds_bytes)");
   WaveScan w;
   w.wlist_off = (uint32_t)__builtin_amdgcn_readfirstlane(
@@ -1072,7 +1075,20 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
     // registers for the whole kernel)
     uint32_t no_hit_hi = __float_as_uint(tmax), no_hit_lo = 0u;
     asm volatile("" : "+v"(no_hit_hi), "+v"(no_hit_lo));
-    lds.best[tid] = ((unsigned long long)no_hit_hi << 32) | no_hit_lo;
+    unsigned long long first_key = ((unsigned long long)no_hit_hi << 32) | no_hit_lo;
+    if (first_direct) {
+      // The sphere at scan position 0 -- the largest of the always-scanned ones, the ground of scenes like the
+      // reference's -- is a candidate of nearly every ray (half of all exact evaluations of the final scene).  Every
+      // lane evaluates it for its own ray here, from registers: no list entry, no reading back of the ray, no
+      // atomic, and the passes over the list run with what is left.
+      const float4 ex0 = sc.exact[0];
+      float t0;
+      if (alive && exact_hit(A, B, a, inv_a, ex0.x, ex0.y, ex0.z, ex0.w, tmin, kFltMax, t0)) {
+        const unsigned long long key0 = ((unsigned long long)__float_as_uint(t0) << 32) | sc.orig[0];
+        if (key0 < first_key) first_key = key0;
+      }
+    }
+    lds.best[tid] = first_key;
 #if RT_EXP == 58
     lds_again_write_b64(lds_address(&lds.best[tid]), ((unsigned long long)no_hit_hi << 32) | no_hit_lo);
 #endif
@@ -1153,7 +1169,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       in_place.sboxes = const_cast<float4 *>(sc.sboxes + 3u * (base / 64u));
       in_place.qboxes = const_cast<float4 *>(sc.qboxes + 3u * (base / 256u));
       in_place.real8 = const_cast<uint8_t *>(kCull ? sc.group_real : sc.group_real + base / 8u);
-      scan_batch<kCull, kCull, true>(sc, in_place, base, span, fr, br, alive, uncullable, w, h, cut);
+      scan_batch<kCull, kCull, true>(sc, in_place, base, span, fr, br, alive, uncullable, w, h, cut, first_direct);
     };
     if (kCull && live_mask != 0ull) {
       // Near batches first, and every hit found narrows what is still worth a visit (rtcore: distance cut).
@@ -1244,7 +1260,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       }
     }
   } else {
-    scan_batch<kCull>(sc, lds, 0u, kCull ? sc.n_pad : sc.n_full, fr, br, alive, uncullable, w, h);
+    scan_batch<kCull>(sc, lds, 0u, kCull ? sc.n_pad : sc.n_full, fr, br, alive, uncullable, w, h, 0.0f, first_direct);
   }
   if (!kCull) h.scan_tests += sc.n;
   const unsigned long long d0 = (kProfile && !RT_SCAN_STAGE) ? tick() : 0ull;
