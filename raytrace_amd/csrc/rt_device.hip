@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
     }
     lds.best[tid] = first_key;
 #if RT_EXP == 58
-    lds_again_write_b64(lds_address(&lds.best[tid]), ((unsigned long long)no_hit_hi << 32) | no_hit_lo);
+    lds_again_write_b64(lds_address(&lds.best[tid]), first_key);
 #endif
   }
   RT_HSTAGE_END(35);
