@@ -1563,6 +1563,22 @@ __global__ __launch_bounds__(kBlockThreads, kCull ? (kBatched ? RT_BATCHED_WAVES
       const uint32_t avail = pool_end - pool_next;
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+#if RT_EXP == 61
+      // ceiling of what a cheaper new-path stage could save: the stage reduced to a dozen instructions (other rays
+      // than the product's, spread over the picture in the same way; every path still has a record of its own)
+      if (!alive && rank < avail) {
+        const uint32_t id = pool_next + rank;
+        g = Rng{id * 0x9e3779b9u};
+        p.x = (float)(id & 2047u) * (1.0f / 2048.0f);
+        p.y = (float)((id >> 11) & 1023u) * (1.0f / 1024.0f);
+        color = v3(1.0f, 1.0f, 1.0f);
+        depth = 0;
+        first_hit = -1;
+        out_index = id;
+        alive = true;
+        pending = kNewPath;
+      }
+#else
       if (!alive && rank < avail) {
         const uint32_t id = pool_next + rank;
         const uint32_t l = id & 63u, ts = id >> 6;
@@ -1595,6 +1611,7 @@ __global__ __launch_bounds__(kBlockThreads, kCull ? (kBatched ? RT_BATCHED_WAVES
           pending = kNewPath;
         }
       }
+#endif
       pool_next += min((uint32_t)__popcll(idle_mask), avail);
     }
     RT_STAGE_END(33);
