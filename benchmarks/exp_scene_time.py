@@ -1,4 +1,5 @@
 """Kernel time of one 1080p frame of random_scene(half_extent) for the device library RT_AMD_DEVICE_LIB names."""
+import hashlib
 import json
 import os
 import sys
@@ -14,7 +15,9 @@ r.upload(sc)
 cam = rt.camera_default(1920, 1080)
 job = rt.Job(1920, 1080, spp, seed=0)
 ms = []
-for _ in range(4):
-    r.render_host(cam, job, debug=False)
+digest = None
+for _ in range(int(os.environ.get("RT_EXP_REPS", "4"))):
+    out = r.render_host(cam, job, debug=False)
     ms.append(round(r.last_kernel_ms(), 3))
-print(json.dumps({"lib": os.environ.get("RT_AMD_DEVICE_LIB", "default"), "spheres": len(sc), "spp": spp, "kernel_ms": ms}))
+    digest = hashlib.sha256(out["rgb8"].tobytes()).hexdigest()[:16]
+print(json.dumps({"lib": os.environ.get("RT_AMD_DEVICE_LIB", "default"), "spheres": len(sc), "spp": spp, "kernel_ms": ms, "image": digest}))

@@ -26,7 +26,7 @@
 // the four box tests of a super-group no lane's ray can touch.  Above the
 // super-groups the same again: four of them form a quarter, and in scenes too
 // large to stay in LDS, which are scanned in batches of `batch_spheres`
-// consecutive scan positions, each batch and each region of eight batches has
+// consecutive scan positions, each batch and each region of kRegionBatches batches has
 // a box (around the boxes below it, widened the same way); a wave skips what
 // none of its rays can touch.
 //
@@ -50,7 +50,10 @@ namespace rtcluster {
 constexpr int kGroup = 8;                      // spheres per group = one chunk of the scan
 constexpr int kSuper = 4;                      // groups per super-group (a box of its own, tested first)
 constexpr int kQuarterSupers = 4;               // super-groups per quarter (128 scan positions: the level between super-group and batch)
-constexpr int kRegionBatches = 8;              // batches per region (the level above the batches of a streamed scene)
+#ifndef RT_REGION_BATCHES
+#define RT_REGION_BATCHES 4
+#endif
+constexpr int kRegionBatches = RT_REGION_BATCHES;              // batches per region (the level above the batches of a streamed scene)
 constexpr double kTinyRadius = 1.0 / 65536.0;   // radius below this: scanned by every ray (keeps sigma1 bounded)
 constexpr double kLargeFactor = 3.0;           // radius > this * median radius: scanned by every ray
 

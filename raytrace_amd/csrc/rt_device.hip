@@ -136,7 +136,10 @@ constexpr int kDrainEvery = 16;       // spheres per round of the scan (two grou
 #define RT_MAX_RESIDENT 2048
 #endif
 constexpr uint32_t kMaxLdsSpheres = RT_MAX_RESIDENT;  // scan positions of a scene that stays in LDS for the whole kernel
-constexpr uint32_t kBatchSpheres = 512;    // larger scenes: scan positions per staged batch (the LDS footprint of
+#ifndef RT_BATCH_SPHERES
+#define RT_BATCH_SPHERES 1024
+#endif
+constexpr uint32_t kBatchSpheres = RT_BATCH_SPHERES;    // larger scenes: scan positions per staged batch (the LDS footprint of
                                            // a batch is that of the reference's final scene)
 constexpr uint32_t kMaxSpheres = 65535;    // list entries are 16-bit
 constexpr int kNumCounters = 18;
@@ -174,8 +177,11 @@ struct DeviceScene {
 __device__ __host__ inline uint32_t batch_pairs(uint32_t n_pad) { return ((n_pad + kBatchSpheres - 1u) / kBatchSpheres + 1u) / 2u; }
 // pairs of quarters (a quarter = four super-groups = 128 scan positions) in `entries` scan positions
 __device__ __host__ inline uint32_t quarter_pairs(uint32_t entries) { return (entries + 255u) / 256u; }
-// ... and behind those the boxes of the regions (kRegionBatches = 8 batches each), again in pairs
-constexpr uint32_t kRegionBatches = 8;
+// ... and behind those the boxes of the regions (kRegionBatches batches each), again in pairs
+#ifndef RT_REGION_BATCHES
+#define RT_REGION_BATCHES 4
+#endif
+constexpr uint32_t kRegionBatches = RT_REGION_BATCHES;
 __device__ __host__ inline uint32_t region_pairs(uint32_t n_pad) { return ((2u * batch_pairs(n_pad) + kRegionBatches - 1u) / kRegionBatches + 1u) / 2u; }
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
@@ -1097,13 +1103,15 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
   if (kBatched) {
     // A scene too large for LDS is scanned where it lies: its pair image, boxes and group sizes are read from
     // global memory (the 16 bytes per sphere of even a 65,535-sphere scene stay in the L2 of every XCD), batch
-    // by batch -- a batch is kBatchSpheres scan positions with a box of its own, eight batches a region with a
+    // by batch -- a batch is kBatchSpheres scan positions with a box of its own, kRegionBatches batches a region with a
     // box above those.  Which batches: those whose box some ray of the WAVE can touch, found by every lane
     // testing its ray against the region boxes and then against the batch boxes of the regions that are
     // touched (two boxes per packed evaluation, read through the scalar cache).  Nothing is shared between the
     // waves of the workgroup, so there is no barrier in the scan and a wave visits only what its own 64 rays
     // need.  (Staging each batch into LDS for the whole workgroup, two barriers per batch, left the vector
     // ALUs idle 60 % of the time.)
+    // (batches of 1024 and more: the largest scene has 64 of them, and the second mask and key are never used)
+    constexpr bool kTwoMasks = (kMaxSpheres + kBatchSpheres) / kBatchSpheres > 64u;
     unsigned long long want_lo = ~0ull, want_hi = ~0ull;   // (without culling: every batch)
     typedef __attribute__((address_space(4))) const float *ScalarFloats;
     const ScalarFloats bb = (ScalarFloats)(uintptr_t)(sc.sboxes + 3u * (sc.n_pad / 64u));
@@ -1118,7 +1126,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
       unsigned long long mine_lo = 0ull, mine_hi = 0ull;
       uint32_t tested = 0;
       if (all_mask == 0ull) {
-        // regions first (eight batches each, two boxes per packed evaluation), then the batch boxes of the regions
+        // regions first (kRegionBatches batches each, two boxes per packed evaluation), then the batch boxes of the regions
         // some ray of the wave can touch; the boxes come through the scalar cache
         const uint32_t n_region_pairs = region_pairs(sc.n_pad);
         uint32_t regions = 0;
@@ -1144,7 +1152,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
             h.fill[9] += (m0 != 0ull ? 1u : 0u) + (m1 != 0ull ? 1u : 0u);   // batches some lane wants
 #endif
             const unsigned long long bits = (unsigned long long)((m0 != 0ull ? 1u : 0u) | (m1 != 0ull ? 2u : 0u));
-            if (q < 32u) mine_lo |= bits << (2u * q);
+            if (!kTwoMasks || q < 32u) mine_lo |= bits << (2u * q);
             else mine_hi |= bits << (2u * q - 64u);
             cur = nxt;
           }
@@ -1198,17 +1206,18 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
         return key;
       };
       float key0 = key_of(w.lane, ((want_lo >> w.lane) & 1ull) != 0ull);
-      float key1 = n_batches > 64u ? key_of(w.lane + 64u, ((want_hi >> w.lane) & 1ull) != 0ull) : __builtin_inff();
+      float key1 = (kTwoMasks && n_batches > 64u) ? key_of(w.lane + 64u, ((want_hi >> w.lane) & 1ull) != 0ull) : __builtin_inff();
       if (w.lane == 0u && (want_lo & 1ull)) key0 = -1.0f;
       // what a hit distance is raised by before it rules a box out; a ray outside the boxes' range is never cut
       const float slack = cut_slack(sc.cut_reach, sc.cut_b, dot(A, A), __builtin_amdgcn_rsqf(a) * 1.001f);
       float cut = __builtin_inff();
+      bool cut_moved = false;   // some lane's cut is below infinity (wave-uniform)
       for (;;) {
-        const float k = __builtin_fminf(key0, key1);
+        const float k = kTwoMasks ? __builtin_fminf(key0, key1) : key0;
         const float kmin = wave_min(k);
         if (!(kmin < __builtin_inff())) break;
         const int j = (int)__builtin_ctzll(__ballot(k == kmin));
-        const bool second = __builtin_amdgcn_readlane((key0 == kmin) ? 0 : 1, j) != 0;
+        const bool second = kTwoMasks && __builtin_amdgcn_readlane((key0 == kmin) ? 0 : 1, j) != 0;
         if ((int)w.lane == j) {
           if (second) key1 = __builtin_inff();
           else key0 = __builtin_inff();
@@ -1219,7 +1228,8 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
         const uint32_t bi = (uint32_t)j + (second ? 64u : 0u);
         const uint32_t base = bi * kBatchSpheres;
         if (base >= sc.n_pad) continue;
-        if (all_mask == 0ull) {
+        // (until a hit has moved some lane's cut, a batch that was wanted is wanted still)
+        if (all_mask == 0ull && cut_moved) {
           bool pass[2];
           float near_bound[2];
           box_pair_scalar(br, load_pair(bi >> 1), pass, near_bound);
@@ -1242,6 +1252,7 @@ __device__ __forceinline__ void closest_hit_scene(const DeviceScene &sc, const S
           drain_wave(sc, w, h);
           const float t_best = __uint_as_float((uint32_t)(lds.best[tid] >> 32));
           cut = rt_fma(t_best, kCutRel, slack);
+          cut_moved = true;
         }
         RT_HSTAGE_EXCLUDE_END(40);
       }
