@@ -186,7 +186,7 @@ def test_rays_outside_the_box_range_in_scenes_with_padded_quarters(renderer, rt,
 
 
 def test_the_largest_scene_and_the_first_too_large(renderer, rt, oracle):
-    """65,535 spheres (128 batches: every bit of both batch masks, scan positions up to 65,535 in the 16-bit list
+    """65,535 spheres (64 batches: every bit of the batch mask, scan positions up to 65,535 in the 16-bit list
     fields): closest hits and a small render against the oracle.  One sphere more, or a much larger sphere whose
     group of its own pushes the padded length past 65,536, is RT_ERR_LIMIT with a message, not a wrong picture."""
     rng = np.random.default_rng(65535)

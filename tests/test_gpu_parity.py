@@ -109,7 +109,7 @@ def test_closest_hit_for_every_list_length_class(renderer, rt, oracle, n):
 
 
 def test_closest_hit_dense_scene_batches(renderer, rt, oracle):
-    """40,004 spheres: the list is scanned in place from global memory, batch by batch (512 scan positions), each
+    """40,004 spheres: the list is scanned in place from global memory, batch by batch (1024 scan positions), each
     wave visiting the batches its own rays can touch; ties keep the lowest index."""
     sc = rt.random_scene(100)
     renderer.upload(sc)
@@ -154,7 +154,7 @@ def test_render_equals_oracle(renderer, rt, oracle, scene, nx, ny, spp):
 @pytest.mark.parametrize("flags", [0, 2])
 def test_render_of_a_scene_too_large_for_lds(renderer, rt, oracle, flags):
     """3,604 spheres (more than stay in LDS): the kernel scans the list where it lies in global memory, in batches
-    of 512 scan positions, every wave on its own (no staging, no barrier), skipping the batches none of its rays
+    of 1024 scan positions, every wave on its own (no staging, no barrier), skipping the batches none of its rays
     can touch; culled and full scan."""
     sc = rt.random_scene(30)
     assert len(sc) > 2048
