@@ -210,8 +210,8 @@ def live_pmc(args, workload):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: final1080 (N = 1, or weak scaling), final4k (N > 1)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1 only; default strong")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
