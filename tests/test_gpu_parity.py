@@ -84,11 +84,13 @@ def test_closest_hit_close_calls(renderer, rt, oracle, scene):
     assert hits > 1000
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 63, 64, 65, 500, 512, 513, 2040, 2048, 2049, 2600])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 63, 64, 65, 500, 512, 513, 1020, 1025, 2040, 2048, 2049, 2600, 3073, 4097, 5121, 8193, 9217])
 def test_closest_hit_for_every_list_length_class(renderer, rt, oracle, n):
-    """List lengths around the group (8), super-group pair (64), batch (512) and LDS-resident (2048) limits:
-    padding, partial groups and the switch to streaming must not change the hit."""
-    full = rt.random_scene(30)
+    """List lengths around the group (8), super-group pair (64), quarter pair (256) and LDS-resident (2048) limits, and,
+    for the scenes scanned in place, around whole batches (1024) and regions (four batches: one, two and three
+    regions, the last one partly filled): padding, partial groups, batches and regions and the switch to scanning
+    in place must not change the hit."""
+    full = rt.random_scene(30 if n <= 3000 else 50)
     rng = np.random.default_rng(100 + n)
     sc = full[np.sort(rng.choice(len(full), size=n, replace=False))].copy()
     renderer.upload(sc)
