@@ -79,6 +79,9 @@ using namespace rtcore;
     if (RT_EXP == N) h.drain_cycles -= tick() - hstage_x0_##N; \
   } while (0)
 
+// RT_EXP 61: the new-path stage reduced to a dozen instructions (other rays than the product's): the ceiling of what a
+// cheaper stage could save
+
 // RT_EXP 51..58: LDS bank-conflict attribution.  One kind of LDS access is issued a second time (same addresses,
 // result thrown away); the growth of SQ_LDS_BANK_CONFLICT and SQ_LDS_IDX_ACTIVE over the plain build is that
 // access kind's share.  51 ray table read by owner (pair filter), 52 pair image read by group (pair filter; scenes
